@@ -1,0 +1,153 @@
+"""Fixed synthetic inputs for parity tests and ``bench.py``.
+
+No dataset or checkpoint ships with the reference (weights are Git-LFS
+pointers, /root/reference/models/kitti_00-06/weights.tar:1-3), so every
+measurement uses:
+
+  * clouds from ``numpy.random.default_rng(1234 + i)`` per scan pair ``i``:
+    KITTI-like (x,y ~ N(0,20^2) m, z ~ N(-1,0.5^2), intensity ~ U[0,1]; source =
+    small rigid motion + 1 cm noise + permutation, mirroring
+    /root/reference/configs/training/kitti_00-06.yaml:20-29) or ModelNet-like
+    (points on a sphere shell; mirrors configs/training/modelnet40.yaml:11-21);
+  * weights in the reference's ``state_dict`` key layout,
+    drawn from a numpy generator so that tests, goldens and the bench rebuild
+    the identical tensors without shipping a 7 MB checkpoint.
+
+The two architecture dictionaries restate the hyper-parameters of
+/root/reference/models/kitti_00-06/model_config.yaml and
+/root/reference/models/modelnet40/model_config.yaml.
+"""
+import copy
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+def _arch(input_dim, npoint, radii, nsamples, k, radius):
+    return {
+        'weights': None, 'input_dim': input_dim, 'point_dim': 3,
+        'label_type': 'POSE3D_DUAL_QUAT', 'model_type': 'DEEPCLR',
+        'params': {
+            'batch_norm': False, 'dropout': 1.0,
+            'cloud_features': {'name': 'SetAbstraction', 'params': {
+                'npoint': [npoint], 'radii': [list(radii)], 'nsamples': [list(nsamples)],
+                'mlps': [[[16, 16, 32], [16, 16, 32]]]}},
+            'merge': {'name': 'MotionEmbedding', 'params': {'k': k, 'radius': radius, 'mlp': [128, 128, 256]}},
+            'output': {'name': 'OutputSimple', 'params': {
+                'mlp': [256, 256, 512, 512, 1024], 'linear': [1024, 512, 256]}},
+        },
+    }
+
+
+KITTI_MODEL_CFG = _arch(4, 1024, (0.5, 1.0), (512, 1024), 20, 10.0)
+MODELNET_MODEL_CFG = _arch(3, 512, (0.1, 0.2), (256, 512), 30, 0.2)
+
+
+def model_cfg(kind: str) -> dict:
+    return copy.deepcopy({'kitti': KITTI_MODEL_CFG, 'modelnet': MODELNET_MODEL_CFG}[kind])
+
+
+def _euler_to_mat(rx: float, ry: float, rz: float) -> np.ndarray:
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    mx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    my = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    mz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return mz @ my @ mx
+
+
+def kitti_like_pair(i: int, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Returns template (n,4), source (n,4), ground-truth 4x4 (source = M * template)."""
+    rng = np.random.default_rng(1234 + i)
+    tmpl = np.empty((n, 4), dtype=np.float64)
+    tmpl[:, 0:2] = rng.normal(0.0, 20.0, size=(n, 2))
+    tmpl[:, 2] = rng.normal(-1.0, 0.5, size=n)
+    tmpl[:, 3] = rng.uniform(0.0, 1.0, size=n)
+    rot = _euler_to_mat(*np.deg2rad(rng.normal(0.0, [0.1, 0.1, 1.0])))
+    trans = rng.normal(0.0, [0.2, 0.02, 0.02])
+    src = tmpl.copy()
+    src[:, :3] = tmpl[:, :3] @ rot.T + trans + rng.normal(0.0, 0.01, size=(n, 3))
+    src = src[rng.permutation(n)]
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = rot, trans
+    return tmpl.astype(np.float32), src.astype(np.float32), m
+
+
+def modelnet_like_pair(i: int, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    rng = np.random.default_rng(1234 + i)
+    p = rng.uniform(-1.0, 1.0, size=(n, 3))
+    p /= np.maximum(np.linalg.norm(p, axis=1, keepdims=True), 1e-9)
+    p *= rng.uniform(0.5, 1.0)
+    rot = _euler_to_mat(*np.deg2rad(rng.uniform(-5.0, 5.0, size=3)))
+    trans = rng.uniform(-0.1, 0.1, size=3)
+    src = p @ rot.T + trans + rng.normal(0.0, 0.02, size=(n, 3))
+    src = src[rng.permutation(n)]
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = rot, trans
+    return p.astype(np.float32), src.astype(np.float32), m
+
+
+def make_batch(kind: str, n_pairs: int, n_points: int, first_pair: int = 0) -> np.ndarray:
+    """(2B, N, C) float32 in the reference batch layout [T0..TB-1, S0..SB-1]
+    (/root/reference/deepclr/data/build.py:82)."""
+    gen = {'kitti': kitti_like_pair, 'modelnet': modelnet_like_pair}[kind]
+    pairs = [gen(first_pair + i, n_points) for i in range(n_pairs)]
+    return np.stack([p[0] for p in pairs] + [p[1] for p in pairs], axis=0)
+
+
+def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
+    """Reference state_dict layout for a model-config mapping."""
+    prm = cfg['params']
+    shapes: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
+    sa = prm['cloud_features']['params']
+    feat_in = cfg['input_dim'] - cfg['point_dim']
+    sa_out = 0
+    for s, spec in enumerate(sa['mlps'][0]):
+        chans = [feat_in + 3, *spec]
+        for j in range(len(spec)):
+            base = '_cloud_layers.0._sa0.mlps.{}.layer{}.conv'.format(s, j)
+            shapes[base + '.weight'] = (chans[j + 1], chans[j], 1, 1)
+            shapes[base + '.bias'] = (chans[j + 1],)
+        sa_out += spec[-1]
+    me = prm['merge']['params']
+    chans = [3 + 2 * sa_out, *me['mlp']]
+    for j in range(len(me['mlp'])):
+        base = '_merge_layers.0._embedding._conv._sequential.{}._sequential.0'.format(j)
+        shapes[base + '.weight'] = (chans[j + 1], chans[j], 1)
+        shapes[base + '.bias'] = (chans[j + 1],)
+    out = prm['output']['params']
+    chans = [3 + me['mlp'][-1], *out['mlp']]
+    for j in range(len(out['mlp'])):
+        base = '_merge_layers.1.conv._sequential.{}._sequential.0'.format(j)
+        shapes[base + '.weight'] = (chans[j + 1], chans[j], 1)
+        shapes[base + '.bias'] = (chans[j + 1],)
+    lin = out['linear']
+    for j in range(len(lin) - 1):
+        base = '_merge_layers.1.linear._sequential.{}._sequential.0'.format(j)
+        shapes[base + '.weight'] = (lin[j + 1], lin[j])
+        shapes[base + '.bias'] = (lin[j + 1],)
+    shapes['_merge_layers.1.output.weight'] = (8, lin[-1])
+    shapes['_merge_layers.1.output.bias'] = (8,)
+    return shapes
+
+
+def random_state_dict(cfg: dict, seed: int = 0, bias_scale: float = 0.05) -> Dict[str, torch.Tensor]:
+    """Xavier-uniform-scaled weights and small non-zero biases from numpy's PCG64.
+
+    Non-zero biases (unlike the reference's zero init, helper.py:23-25) so that
+    every bias path of the kernels is exercised by the parity tests.
+    """
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+    for name, shape in state_dict_shapes(cfg).items():
+        if name.endswith('.weight'):
+            fan_out, fan_in = shape[0], shape[1]
+            bound = np.sqrt(6.0 / (fan_in + fan_out))
+            arr = rng.uniform(-bound, bound, size=shape)
+        else:
+            arr = rng.uniform(-bias_scale, bias_scale, size=shape)
+            if name == '_merge_layers.1.output.bias':
+                arr[0] += 1.0
+        sd[name] = torch.from_numpy(arr.astype(np.float32))
+    return sd
