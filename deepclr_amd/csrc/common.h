@@ -1,0 +1,90 @@
+// Shared device/host helpers for libdeepclr_amd (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/deepclr_amd.h"
+
+#define DCLR_WAVE 64
+
+#define DCLR_REQUIRE(cond)             \
+    do {                               \
+        if (!(cond)) return DCLR_E_INVALID; \
+    } while (0)
+
+static inline int dclr_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DCLR_OK : -(1000 + (int)e);
+}
+
+// ---- frozen distance recipe (include/deepclr_amd.h): (dx*dx + dy*dy) + dz*dz, no contraction.
+// The whole library is built with -ffp-contract=off; MLP code asks for FMA explicitly (fmaf).
+__device__ __forceinline__ float dclr_sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+// ---- DPP wave reductions over u32 (result broadcast through an SGPR).
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dclr_dpp(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+#define DCLR_DPP_ROW_SHR(n) (0x110 + (n))
+#define DCLR_DPP_ROW_BCAST15 0x142
+#define DCLR_DPP_ROW_BCAST31 0x143
+
+__device__ __forceinline__ uint32_t dclr_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t dclr_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// Inclusive "scan to the right" with an idempotent op: lane 63 ends up with the wave result.
+__device__ __forceinline__ uint32_t dclr_wave_max_u32(uint32_t v) {
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc, 0xf>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint32_t dclr_wave_min_u32(uint32_t v) {
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc, 0xf>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Same over the first 16 lanes only (one DPP row): lane 15 holds the result.
+__device__ __forceinline__ uint32_t dclr_row16_max_u32(uint32_t v) {
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+__device__ __forceinline__ uint32_t dclr_row16_min_u32(uint32_t v) {
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+// Wave max over f32 for values >= 0 (bit pattern order == value order).
+__device__ __forceinline__ float dclr_wave_max_nonneg(float v) {
+    return __uint_as_float(dclr_wave_max_u32(__float_as_uint(v)));
+}
+
+__device__ __forceinline__ int dclr_lane() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ uint32_t dclr_lanemask_lt_popc(uint64_t mask) {
+    // number of set bits of `mask` strictly below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}

@@ -1,0 +1,194 @@
+// Dense MLP layers for gfx950: weight packing, Y = act(X W^T + b) on fp32 MFMA, small FC tail.
+//
+// Replaces the cuDNN/cuBLAS 1x1 Conv1d / Linear calls behind the reference's helper modules
+// (/root/reference/deepclr/models/helper.py:11-65: affine + ReLU after every layer) for the pose head
+// (OutputSimple.forward, /root/reference/deepclr/models/deepclr.py:284-294) and for the per-point
+// part of the flow embedding's first layer. Activations are point-major rows, so a 1x1 conv is a
+// plain row-major GEMM and the max over points is a column maximum.
+#include "mma.h"
+
+namespace {
+
+// ---- weight packing ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(int n_out, int k_in, const float *__restrict__ w,
+                                                          const int32_t *__restrict__ kmap, int kp, int np,
+                                                          float *__restrict__ packed) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)np * kp) return;
+    const int q = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const size_t grp = e >> 8;                 // ntile * KG + g
+    const int kg = kp / 8;
+    const int g = (int)(grp % kg), ntile = (int)(grp / kg);
+    const int n = ntile * 32 + (lane & 31);
+    const int k = g * 8 + 4 * (lane >> 5) + q;
+    int col = kmap ? kmap[k] : (k < k_in ? k : -1);
+    float v = 0.f;
+    if (n < n_out && col >= 0 && col < k_in) v = w[(size_t)n * k_in + col];
+    packed[e] = v;
+}
+
+// ---- Y = act(X W^T + b) ----------------------------------------------------------------------------
+// Workgroup: 64 rows x 128 columns, 4 waves; wave w owns column tile w (32 columns) and both 32-row
+// tiles. X is staged through LDS in 32-wide K chunks (double buffered, one barrier per chunk);
+// packed weights come straight from L2 as coalesced 1 KiB fragments, prefetched one chunk ahead.
+constexpr int LIN_BM = 64, LIN_BK = 32, LIN_WAVES = 4;
+constexpr int LIN_STRIDE = dclr_lds_stride(LIN_BK);       // 36 floats
+
+__global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, int kp, const float *__restrict__ x,
+                                                                int ldx, const float4 *__restrict__ wp,
+                                                                const float *__restrict__ bias, int relu,
+                                                                float *__restrict__ y, int ldy,
+                                                                float *__restrict__ colmax, int rows_per_group) {
+    __shared__ __attribute__((aligned(16))) float tile[2][LIN_BM * LIN_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int m0 = blockIdx.x * LIN_BM;
+    const int ntile = blockIdx.y * LIN_WAVES + wave;
+    const int n_tiles = (n + 31) / 32;
+    const bool active = ntile < n_tiles;                  // wave-uniform
+    const int kg_total = kp / 8;
+    const int n_chunks = (kp + LIN_BK - 1) / LIN_BK;
+
+    // staging role: thread -> (row, 16-byte column) of the 64 x 32 chunk, two rows per thread
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float *xs0 = x + (size_t)(m0 + srow) * ldx + scol;
+    const float *xs1 = xs0 + (size_t)32 * ldx;
+
+    auto fetch = [&](int chunk, float4 &r0, float4 &r1) {
+        const int kc = chunk * LIN_BK + scol;
+        r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kc < kp) {
+            r0 = *reinterpret_cast<const float4 *>(xs0 + chunk * LIN_BK);
+            r1 = *reinterpret_cast<const float4 *>(xs1 + chunk * LIN_BK);
+        }
+    };
+    auto stash = [&](int buf, const float4 &r0, const float4 &r1) {
+        *reinterpret_cast<float4 *>(&tile[buf][srow * LIN_STRIDE + scol]) = r0;
+        *reinterpret_cast<float4 *>(&tile[buf][(srow + 32) * LIN_STRIDE + scol]) = r1;
+    };
+
+    dclr_f32x16 acc[2][1];
+    acc[0][0] = dclr_zero16();
+    acc[1][0] = dclr_zero16();
+
+    const float4 *w_lane = wp + ((size_t)(active ? ntile : 0) * kg_total) * 64 + lane;
+
+    float4 r0, r1;
+    fetch(0, r0, r1);
+    stash(0, r0, r1);
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) fetch(c + 1, r0, r1);
+        if (active) {
+            const int g0 = c * (LIN_BK / 8);
+            const int g1 = g0 + LIN_BK / 8 < kg_total ? g0 + LIN_BK / 8 : kg_total;
+            const float *a_lds = &tile[buf][j * LIN_STRIDE + 4 * h];
+            for (int g = g0; g < g1; ++g)
+                dclr_mma_group<2, 1>(acc, a_lds, LIN_STRIDE, g - g0, w_lane + (size_t)g * 64, 0);
+        }
+        if (c + 1 < n_chunks) stash(buf ^ 1, r0, r1);
+        __syncthreads();
+    }
+
+    if (!active) return;
+    const int col = ntile * 32 + j;
+    const float bv = (bias && col < n) ? bias[col] : 0.f;
+    if (colmax) {
+        float mx = 0.f;                                   // relu is required: values >= 0
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][0][r] + bv);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (h == 0 && col < n)
+            atomicMax(reinterpret_cast<unsigned int *>(colmax + (size_t)(m0 / rows_per_group) * n + col),
+                      __float_as_uint(mx));
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + t * 32 + dclr_acc_row(r, h);
+            float v = acc[t][0][r] + bv;
+            if (relu) v = fmaxf(v, 0.f);
+            if (col < n) y[(size_t)row * ldy + col] = v;
+        }
+}
+
+// ---- FC tail: a handful of rows (one per scan pair) -------------------------------------------------
+// One wave per output column; lanes stride over K with coalesced weight reads; rows in chunks of 8.
+constexpr int FC_WAVES = 4, FC_ROWS = 8;
+
+__global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, const float *__restrict__ x,
+                                                           const float *__restrict__ w,
+                                                           const float *__restrict__ bias, int act,
+                                                           float *__restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.x * FC_WAVES + wave;
+    if (col >= n) return;
+    const float *wr = w + (size_t)col * k;
+    for (int r0 = 0; r0 < m; r0 += FC_ROWS) {
+        float acc[FC_ROWS];
+#pragma unroll
+        for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
+        for (int kk = lane; kk < k; kk += 64) {
+            const float wv = wr[kk];
+#pragma unroll
+            for (int r = 0; r < FC_ROWS; ++r)
+                if (r0 + r < m) acc[r] = fmaf(wv, x[(size_t)(r0 + r) * k + kk], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < FC_ROWS; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && r0 + r < m) {
+                v += bias ? bias[col] : 0.f;
+                if (act == 1) v = fmaxf(v, 0.f);
+                else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
+                else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
+                y[(size_t)(r0 + r) * n + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dclr_pack_weight(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int np,
+                                float *packed, dclr_stream_t stream) {
+    DCLR_REQUIRE(n_out > 0 && k_in > 0 && w && packed && kp > 0 && np > 0);
+    DCLR_REQUIRE(kp % 8 == 0 && np % 32 == 0 && np >= n_out && (kmap || kp >= k_in));
+    const size_t total = (size_t)np * kp;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n_out, k_in, w, kmap, kp, np, packed);
+    return dclr_launch_status();
+}
+
+extern "C" int dclr_linear(int m, int n, int kp, const float *x, int ldx, const float *w_packed,
+                           const float *bias, int relu, float *y, int ldy, float *colmax,
+                           int rows_per_group, dclr_stream_t stream) {
+    DCLR_REQUIRE(m > 0 && n > 0 && kp > 0 && x && w_packed && (y || colmax));
+    DCLR_REQUIRE(m % LIN_BM == 0 && kp % 8 == 0 && ldx % 4 == 0 && ldx >= kp);
+    DCLR_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0);
+    if (colmax) DCLR_REQUIRE(relu && rows_per_group > 0 && rows_per_group % LIN_BM == 0 && m % rows_per_group == 0);
+    else DCLR_REQUIRE(ldy >= n);
+    const int n_tiles = (n + 31) / 32;
+    dim3 grid(m / LIN_BM, (n_tiles + LIN_WAVES - 1) / LIN_WAVES);
+    DCLR_REQUIRE(grid.y <= 65535);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n, kp, x, ldx,
+                       reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax, rows_per_group);
+    return dclr_launch_status();
+}
+
+extern "C" int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act,
+                       float *y, dclr_stream_t stream) {
+    DCLR_REQUIRE(m > 0 && n > 0 && k > 0 && x && w && y && act >= 0 && act <= 3);
+    hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES), dim3(FC_WAVES * 64), 0,
+                       (hipStream_t)stream, m, n, k, x, w, bias, act, y);
+    return dclr_launch_status();
+}

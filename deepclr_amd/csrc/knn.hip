@@ -1,0 +1,158 @@
+// Batched k-nearest-neighbour search for gfx950.
+//
+// Replaces torch_cluster.knn as DeepCLR calls it (/root/reference/deepclr/models/deepclr.py:164-166):
+// for every query (template point) the k nearest candidates (source points) of the same pair,
+// ascending squared distance, equal distances in ascending candidate index -- the order the
+// published torch-cluster 1.5.9 GPU kernel's strict-">" insertion list yields (oracle/primitives.c).
+//
+// One wave serves a run of queries against one candidate cloud: each lane keeps CPL candidates
+// (index c*64 + lane) in registers for the whole run, so a query costs CPL distance evaluations
+// per lane plus k selection rounds; a round is a two-step DPP reduction (min distance bits, then
+// min index among equals) and only re-scans registers.
+#include "common.h"
+
+namespace {
+
+constexpr int KNN_WAVES = 4;     // waves per workgroup
+constexpr int KNN_QRUN = 8;      // queries per wave
+constexpr uint32_t KNN_INF = 0x7F800000u;
+
+struct KnnXyzSource {            // (clouds*n, 3) packed points
+    const float *base;
+    __device__ __forceinline__ void load(size_t cloud, int n, int i, float &x, float &y, float &z) const {
+        const float *p = base + (cloud * n + i) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+    }
+};
+
+struct KnnRowSource {            // feature rows F: xyz at columns 64..66 of a 68-float row
+    const float *base;
+    __device__ __forceinline__ void load(size_t cloud, int n, int i, float &x, float &y, float &z) const {
+        const float *p = base + (cloud * n + i) * DCLR_F_STRIDE + 64;
+        x = p[0]; y = p[1]; z = p[2];
+    }
+};
+
+template <int CPL, typename Src, typename OutFn>
+__device__ __forceinline__ void knn_run(const Src &cand, size_t cand_cloud, int nx, const Src &query,
+                                        size_t query_cloud, int ny, int q0, int q1, int k, OutFn out) {
+    const int lane = dclr_lane();
+    float px[CPL], py[CPL], pz[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int i = c * 64 + lane;
+        px[c] = py[c] = pz[c] = 0.f;
+        if (i < nx) cand.load(cand_cloud, nx, i, px[c], py[c], pz[c]);
+    }
+    for (int q = q0; q < q1; ++q) {
+        float qx, qy, qz;
+        query.load(query_cloud, ny, q, qx, qy, qz);          // wave-uniform
+        uint32_t d[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int i = c * 64 + lane;
+            // (candidate - query), accumulated x,y,z: the published kernel's order
+            d[c] = i < nx ? __float_as_uint(dclr_sqdist(px[c], py[c], pz[c], qx, qy, qz)) : KNN_INF;
+        }
+        for (int s = 0; s < k; ++s) {
+            uint32_t lmin = d[0];
+            int lc = 0;
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) {
+                const bool lt = d[c] < lmin;
+                lc = lt ? c : lc;
+                lmin = lt ? d[c] : lmin;
+            }
+            const uint32_t li = (uint32_t)(lc * 64 + lane);
+            const uint32_t wmin = dclr_wave_min_u32(lmin);
+            const uint32_t widx = dclr_wave_min_u32(lmin == wmin ? li : 0xFFFFFFFFu);
+            if (lane == 0) out(q, s, wmin >= KNN_INF ? -1 : (int)widx);
+            const int wc = (int)(widx >> 6), wl = (int)(widx & 63);
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) d[c] = (lane == wl && c == wc) ? KNN_INF : d[c];
+        }
+    }
+}
+
+template <int CPL>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_xyz_kernel(int nx, int ny, int k,
+                                                                 const float *__restrict__ x,
+                                                                 const float *__restrict__ y,
+                                                                 int64_t *__restrict__ row,
+                                                                 int64_t *__restrict__ col) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t bi = blockIdx.y;
+    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
+    const int q1 = q0 + KNN_QRUN < ny ? q0 + KNN_QRUN : ny;
+    if (q0 >= ny) return;
+    KnnXyzSource cs{x}, qs{y};
+    knn_run<CPL>(cs, bi, nx, qs, bi, ny, q0, q1, k, [&](int q, int s, int ci) {
+        const size_t gq = bi * ny + q;
+        row[gq * k + s] = ci < 0 ? -1 : (int64_t)gq;
+        col[gq * k + s] = ci < 0 ? -1 : (int64_t)(bi * nx + ci);
+    });
+}
+
+template <int CPL>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int pairs, int npoint, int k,
+                                                                  const float *__restrict__ f_rows,
+                                                                  int32_t *__restrict__ knn_idx) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t bi = blockIdx.y;
+    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
+    const int q1 = q0 + KNN_QRUN < npoint ? q0 + KNN_QRUN : npoint;
+    if (q0 >= npoint) return;
+    KnnRowSource src{f_rows};
+    knn_run<CPL>(src, bi + pairs, npoint, src, bi, npoint, q0, q1, k, [&](int q, int s, int ci) {
+        knn_idx[(bi * npoint + q) * k + s] = ci;
+    });
+}
+
+template <template <int> class Launcher, typename... Args>
+int knn_dispatch(int nx, Args... args) {
+    if (nx <= 64) return Launcher<1>::go(args...);
+    if (nx <= 128) return Launcher<2>::go(args...);
+    if (nx <= 256) return Launcher<4>::go(args...);
+    if (nx <= 512) return Launcher<8>::go(args...);
+    if (nx <= 1024) return Launcher<16>::go(args...);
+    if (nx <= 2048) return Launcher<32>::go(args...);
+    if (nx <= 4096) return Launcher<64>::go(args...);
+    return DCLR_E_UNSUPPORTED;
+}
+
+template <int CPL>
+struct XyzLauncher {
+    static int go(int b, int nx, int ny, int k, const float *x, const float *y, int64_t *row, int64_t *col,
+                  hipStream_t s) {
+        const int per_wg = KNN_WAVES * KNN_QRUN;
+        hipLaunchKernelGGL((knn_xyz_kernel<CPL>), dim3((ny + per_wg - 1) / per_wg, b), dim3(KNN_WAVES * 64),
+                           0, s, nx, ny, k, x, y, row, col);
+        return dclr_launch_status();
+    }
+};
+
+template <int CPL>
+struct RowsLauncher {
+    static int go(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx, hipStream_t s) {
+        const int per_wg = KNN_WAVES * KNN_QRUN;
+        hipLaunchKernelGGL((knn_rows_kernel<CPL>), dim3((npoint + per_wg - 1) / per_wg, pairs),
+                           dim3(KNN_WAVES * 64), 0, s, pairs, npoint, k, f_rows, knn_idx);
+        return dclr_launch_status();
+    }
+};
+
+}  // namespace
+
+extern "C" int dclr_knn(int b, int nx, int ny, int k, const float *x, const float *y, int64_t *row,
+                        int64_t *col, dclr_stream_t stream) {
+    DCLR_REQUIRE(b > 0 && nx > 0 && ny > 0 && x && y && row && col && b <= 65535);
+    DCLR_REQUIRE(k >= 1 && k <= 64 && nx >= k);
+    return knn_dispatch<XyzLauncher>(nx, b, nx, ny, k, x, y, row, col, (hipStream_t)stream);
+}
+
+extern "C" int dclr_knn_rows(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx,
+                             dclr_stream_t stream) {
+    DCLR_REQUIRE(pairs > 0 && npoint > 0 && f_rows && knn_idx && pairs <= 65535);
+    DCLR_REQUIRE(k >= 1 && k <= 64 && npoint >= k);
+    return knn_dispatch<RowsLauncher>(npoint, pairs, npoint, k, f_rows, knn_idx, (hipStream_t)stream);
+}

@@ -1,0 +1,56 @@
+// fp32 MFMA building blocks shared by the dense-MLP kernels (gfx950).
+//
+// Instruction: v_mfma_f32_32x32x2_f32 -- exact binary32 (a k-ordered fmaf chain), 64 cycles per
+// issue per SIMD = the f32 peak of the chip (MI355X_MICROARCH.md, "Matrix cores"). The pose tolerance
+// (1e-4 on the 4x4, BASELINE.json) rules out plain bf16 inputs for the 131->...->1024 chains.
+//
+// Operand maps (lane l, i/j = l & 31, h = l >> 5):
+//   A (32 x 2):  A[i][h]         B (2 x 32):  B[h][j]
+//   C/D (32x32): 16 regs, column j = l & 31, row = (r & 3) + 8*(r >> 2) + 4*h
+//
+// K is consumed in groups of 8: MFMA q (0..3) of a group multiplies k = 8*g + 4*h + q, so one
+// 16-byte read per lane feeds four MFMAs on either side:
+//   activations  X[row][8g + 4h .. +3]                      (ds_read_b128 from a row-major LDS tile)
+//   weights      packed[(ntile*KG + g)*64 + lane] (float4)  (one coalesced 1 KiB load per wave)
+// The sum over k is thereby re-ordered inside each group of 8; both operands use the same order.
+#pragma once
+#include "common.h"
+
+typedef float dclr_f32x16 __attribute__((ext_vector_type(16)));
+
+// LDS row stride (floats) for a tile holding `kp` columns: kp rounded to 8, plus 4, so that
+// stride/4 is odd and every 16-lane group of a ds_read_b128 hits 16 distinct 16-byte slots.
+__host__ __device__ constexpr int dclr_lds_stride(int kp) { return ((kp + 7) / 8) * 8 + 4; }
+
+__device__ __forceinline__ dclr_f32x16 dclr_zero16() {
+    dclr_f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// One k-group (8 values of K) for MT row tiles x NT column tiles.
+//   a_lds  : this lane's row inside row-tile 0, already offset by 4*h  (tile t adds t*32*stride)
+//   w_lane : packed weights of column-tile 0, group g, this lane; column-tile u adds u*ntile_stride float4
+template <int MT, int NT>
+__device__ __forceinline__ void dclr_mma_group(dclr_f32x16 (&acc)[MT][NT], const float *a_lds, int stride,
+                                               int g, const float4 *w_lane, int ntile_stride) {
+    float4 b[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) b[u] = w_lane[(size_t)u * ntile_stride];
+    float4 a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 32 * stride + 8 * g);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+        }
+}
+
+// Row of accumulator register r for lane-half h inside a 32-row tile.
+__device__ __forceinline__ int dclr_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

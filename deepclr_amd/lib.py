@@ -1,0 +1,80 @@
+"""ctypes binding of libdeepclr_amd.so (include/deepclr_amd.h).
+
+The product path has no CPU fallback: if the library is missing or a tensor is
+not on a HIP device the call raises, exactly as the reference's wrappers raise
+through TORCH_CHECK for non-CUDA tensors (/root/reference/extern/pointnet2.patch:97-99).
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'libdeepclr_amd.so')
+
+_i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes; every entry point declared in include/deepclr_amd.h
+SIGNATURES = {
+    'dclr_version': [],
+    'dclr_error_string': [_i],
+    'dclr_furthest_point_sampling': [_i, _i, _i, _p, _p, _p, _p],
+    'dclr_gather_points': [_i, _i, _i, _i, _p, _p, _p, _p],
+    'dclr_ball_query': [_i, _i, _i, _f, _i, _p, _p, _p, _p],
+    'dclr_group_points': [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    'dclr_knn': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    'dclr_fps_clouds': [_i, _i, _i, _i, _p, _p, _p],
+    'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
+    'dclr_channels_to_rows': [_i, _i, _i, _i, _i, _p, _p, _p],
+    'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],
+    'dclr_linear': [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p],
+    'dclr_knn_rows': [_i, _i, _i, _p, _p, _p],
+    'dclr_flow_embedding_fused': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dclr_fc': [_i, _i, _i, _p, _p, _p, _i, _p, _p],
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "deepclr_amd: {} is missing. Build it with `python -m deepclr_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback.".format(LIB_PATH))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == 'dclr_error_string' else _i
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().dclr_error_string(code).decode()
+        raise RuntimeError("{} failed: {} (code {})".format(what, msg, code))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Contract of the reference wrappers: GPU tensor, contiguous (pointnet2.patch:8-10 CHECK_INPUT)."""
+    if not t.is_cuda:
+        raise RuntimeError("{} must be a GPU tensor (deepclr_amd has no CPU path)".format(name))
+    if t.dtype != torch.float32:
+        raise RuntimeError("{} must be float32".format(name))
+    if not t.is_contiguous():
+        raise RuntimeError("{} must be contiguous".format(name))
+    return t
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()

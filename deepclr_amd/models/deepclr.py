@@ -1,0 +1,355 @@
+"""DeepCLR forward pass on the fused HIP kernels.
+
+Mirrors the module tree, constructor arguments, ``state_dict`` keys and the
+``forward(x, is_feat, m, y, debug)`` / ``cloud_features(x, m)`` contract of
+/root/reference/deepclr/models/deepclr.py (SetAbstraction 48-94, MotionEmbedding 176-246,
+OutputSimple 249-294, DeepCLR 442-521, name-based factory 412-427). Internally the three stages
+exchange point-major rows (F: 68 floats, E: 264 floats per point, include/deepclr_amd.h);
+reference-layout tensors exist only at the API edge (``cloud_features`` output, ``is_feat`` input,
+and the per-module ``forward`` methods the reference's layer tests call).
+
+Out of scope here: losses (a ground truth ``y`` raises), backward, batch norm.
+"""
+import abc
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import Config
+from ..labels import LabelType
+from ..pointnet2 import PointnetSAModuleMSG
+from .base import BaseModel
+from .helper import Conv1dMultiLayer, LinearMultiLayer, PackedCache
+
+FEAT = 64          # feature columns of a cloud-feature row (two 32-channel scales)
+
+
+class DeepCLRModule(nn.Module, metaclass=abc.ABCMeta):
+    """Base of the configurable sub-networks; looked up by class name (reference: deepclr.py:412-414)."""
+
+    @abc.abstractmethod
+    def output_dim(self) -> int:
+        raise NotImplementedError
+
+
+def _subclass_by_name(base: type, name: str) -> Optional[type]:
+    for sub in base.__subclasses__():
+        if sub.__name__ == name:
+            return sub
+        found = _subclass_by_name(sub, name)
+        if found is not None:
+            return found
+    return None
+
+
+def _init_module(cfg: Config, *args: Any, **kwargs: Any) -> DeepCLRModule:
+    cls = _subclass_by_name(DeepCLRModule, cfg.name)
+    if cls is None:
+        raise NotImplementedError("Class '{}' not found as subclass of '{}'".format(cfg.name, DeepCLRModule.__name__))
+    return cls(*args, **cfg.params, **kwargs)
+
+
+# --------------------------------------------------------------------------------------------------
+# set abstraction
+# --------------------------------------------------------------------------------------------------
+class SetAbstraction(DeepCLRModule):
+    """Per-cloud feature extraction (reference: deepclr.py:48-94); one level (all shipped configs)."""
+
+    def __init__(self, input_dim: int, point_dim: int, mlps: List[List[List[int]]], npoint: List[int],
+                 radii: List[List[float]], nsamples: List[List[int]], batch_norm: bool = False, **_kwargs: Any):
+        super().__init__()
+        assert point_dim == 3
+        assert len(mlps) == len(npoint) == len(radii) == len(nsamples)
+        if len(mlps) != 1:
+            raise NotImplementedError("a second set-abstraction level is not used by any shipped model")
+        feat_in = input_dim - point_dim
+        self._input_dim = input_dim
+        self._output_feat_dim = int(np.sum([spec[-1] for spec in mlps[-1]]))
+        self._sa0 = PointnetSAModuleMSG(npoint=npoint[0], radii=radii[0], nsamples=nsamples[0],
+                                        mlps=[[feat_in, *spec] for spec in mlps[0]], use_xyz=True, bn=batch_norm)
+        self.npoint = npoint[0]
+
+    def output_dim(self) -> int:
+        return 3 + self._output_feat_dim
+
+    def forward_rows(self, clouds: torch.Tensor) -> torch.Tensor:
+        """(2B, N, C) point-major clouds -> rows F."""
+        return self._sa0.forward_rows(clouds)
+
+    def forward(self, clouds: torch.Tensor, *_args: Any) -> torch.Tensor:
+        """(2B, C, N) channel-major clouds -> (2B, 3 + feat, npoint), as the reference module."""
+        rows = self.forward_rows(clouds.transpose(1, 2).contiguous())
+        return ops.rows_to_channels(rows, clouds.shape[0], self.npoint, self._output_feat_dim)
+
+
+# --------------------------------------------------------------------------------------------------
+# flow embedding
+# --------------------------------------------------------------------------------------------------
+class MotionEmbeddingBase(nn.Module):
+    """kNN grouping + shared MLP + radius mask + max (reference: deepclr.py:176-231)."""
+
+    def __init__(self, input_dim: int, point_dim: int, k: int, radius: float, mlp: List[int],
+                 append_features: bool = True, batch_norm: bool = False, **_kwargs: Any):
+        super().__init__()
+        if k == 0:
+            raise NotImplementedError("global grouping (k == 0) is not used by any shipped model")
+        if not 1 <= k <= 32:
+            raise NotImplementedError("the fused flow-embedding kernel pads each neighbourhood to 32 rows (k <= 32)")
+        if list(mlp) != [128, 128, 256]:
+            raise NotImplementedError("the fused flow-embedding kernel is built for mlp [128, 128, 256]")
+        self._point_dim = point_dim
+        self._feat_dim = input_dim - point_dim
+        if self._feat_dim > FEAT:
+            raise NotImplementedError("at most {} feature channels per point".format(FEAT))
+        self._append_features = append_features
+        self._k, self._radius = int(k), float(radius)
+        c_in = point_dim + (2 if append_features else 1) * self._feat_dim
+        self._conv = Conv1dMultiLayer([c_in, *mlp], batch_norm=batch_norm)
+        self._cache = PackedCache()
+
+    def output_dim(self) -> int:
+        return self._point_dim + self._conv.output_dim()
+
+    def _packed(self):
+        def build():
+            (w1, b1), (w2, b2), (w3, b3) = self._conv.affine_params()
+            w1 = w1.detach().reshape(w1.shape[0], -1)
+            d, f = self._point_dim, self._feat_dim
+            dev = w1.device
+            kmap = torch.full((FEAT,), -1, dtype=torch.int32, device=dev)
+            kmap[:f] = torch.arange(f, dtype=torch.int32, device=dev)
+            if self._append_features:
+                w_t, w_s = w1[:, d:d + f], w1[:, d + f:d + 2 * f]
+            else:                                   # merged = [pos_diff, feat_s - feat_t] (deepclr.py:212-213)
+                w_t, w_s = -w1[:, d:d + f], w1[:, d:d + f]
+            return {
+                'w1a': w1[:, :d].contiguous(), 'b1': b1.detach().contiguous(),
+                'wt': ops.pack_weight(w_t.contiguous(), FEAT, kmap), 'ws': ops.pack_weight(w_s.contiguous(), FEAT, kmap),
+                'w2p': ops.pack_weight(w2, 128), 'b2': b2.detach().contiguous(),
+                'w3p': ops.pack_weight(w3, 128), 'b3': b3.detach().contiguous(),
+            }
+        return self._cache.get(list(self.parameters()), build)
+
+    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int) -> torch.Tensor:
+        """rows F of [templates..., sources...] -> rows E (pairs*npoint, 264)."""
+        p = self._packed()
+        half = pairs * npoint
+        pt = ops.linear(f_rows[:half], p['wt'], None, 128, FEAT, relu=False)
+        ps = ops.linear(f_rows[half:], p['ws'], None, 128, FEAT, relu=False)
+        knn_idx = ops.knn_rows(f_rows, pairs, npoint, self._k)
+        return ops.flow_embedding_fused(f_rows, knn_idx, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'],
+                                        p['w3p'], p['b3'], self._radius)
+
+    def forward(self, clouds0: torch.Tensor, clouds1: torch.Tensor) -> torch.Tensor:
+        """(B, 3+F, P) template / source feature clouds -> (B, 3+256, P), as the reference module."""
+        b, _, npoint = clouds0.shape
+        f_rows = ops.channels_to_rows(torch.cat((clouds0, clouds1), dim=0).contiguous(), ops.F_STRIDE)
+        e_rows = self.forward_rows(f_rows, b, npoint)
+        return ops.rows_to_channels(e_rows, b, npoint, 256)
+
+
+class MotionEmbedding(DeepCLRModule):
+    """Batch layout [T0..TB-1, S0..SB-1] (reference: deepclr.py:234-246)."""
+
+    def __init__(self, **kwargs: Any):
+        super().__init__()
+        self._embedding = MotionEmbeddingBase(**kwargs)
+
+    def output_dim(self) -> int:
+        return self._embedding.output_dim()
+
+    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int) -> torch.Tensor:
+        return self._embedding.forward_rows(f_rows, pairs, npoint)
+
+    def forward(self, clouds: torch.Tensor) -> torch.Tensor:
+        half = clouds.shape[0] // 2
+        return self._embedding(clouds[:half], clouds[half:])
+
+
+# --------------------------------------------------------------------------------------------------
+# pose head
+# --------------------------------------------------------------------------------------------------
+class OutputSimple(DeepCLRModule):
+    """Mini-PointNet + fully connected regression head (reference: deepclr.py:249-294)."""
+
+    def __init__(self, input_dim: int, label_type: LabelType, mlp: List[int], linear: List[int],
+                 batch_norm: bool = False, dropout: float = 1.0, **_kwargs: Any):
+        super().__init__()
+        if input_dim != 3 + 256:
+            raise NotImplementedError("the head consumes flow-embedding rows E (3 + 256 channels)")
+        self._label_type = label_type
+        self.conv = Conv1dMultiLayer([input_dim, *mlp], batch_norm=batch_norm)
+        self.linear = LinearMultiLayer(linear, batch_norm=batch_norm, dropout_keep=dropout, dropout_last=True)
+        self.output = nn.Linear(linear[-1], label_type.dim, bias=True)
+        nn.init.xavier_uniform_(self.output.weight)
+        if label_type.bias is not None:
+            with torch.no_grad():
+                self.output.bias.copy_(torch.tensor(label_type.bias, dtype=torch.float32))
+        self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
+        self._cache = PackedCache()
+
+    def output_dim(self) -> int:
+        return self._label_type.dim
+
+    def _packed(self):
+        def build():
+            layers = []
+            for i, (w, b) in enumerate(self.conv.affine_params()):
+                n, k_in = w.shape[0], w.shape[1]
+                if i == 0:      # reference column order [xyz | feat] -> row order [feat | xyz | pad]
+                    kp = ops.E_STRIDE
+                    kmap = torch.full((kp,), -1, dtype=torch.int32, device=w.device)
+                    kmap[:256] = torch.arange(3, 259, dtype=torch.int32, device=w.device)
+                    kmap[256:259] = torch.arange(0, 3, dtype=torch.int32, device=w.device)
+                    wp = ops.pack_weight(w, kp, kmap)
+                else:
+                    kp = (k_in + 7) // 8 * 8
+                    wp = ops.pack_weight(w, kp)
+                layers.append((wp, b.detach().contiguous(), n, kp))
+            return layers
+        return self._cache.get(list(self.conv.parameters()), build)
+
+    def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
+        layers = self._packed()
+        h = e_rows
+        for wp, b, n, kp in layers[:-1]:
+            h = ops.linear(h, wp, b, n, kp, relu=True, ldy=(n + 7) // 8 * 8)
+        wp, b, n, kp = layers[-1]
+        g = ops.linear(h, wp, b, n, kp, relu=True, colmax_groups=pairs)      # conv + max over points
+        g = self.linear(g)
+        return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, 259, P) -> (B, label_dim)."""
+        return self.forward_rows(ops.channels_to_rows(x.contiguous(), ops.E_STRIDE), x.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------
+# losses: parameter holders only (state_dict compatibility); evaluating them is out of scope
+# --------------------------------------------------------------------------------------------------
+class DeepCLRLoss(DeepCLRModule, metaclass=abc.ABCMeta):
+    def output_dim(self) -> int:
+        return 1
+
+    def get_weights(self) -> Dict:
+        return {}
+
+    def forward(self, *_args: Any, **_kwargs: Any) -> torch.Tensor:
+        raise NotImplementedError("loss evaluation (training path) is outside the MI355X forward hot path")
+
+
+class TransformLoss(DeepCLRLoss):
+    def __init__(self, label_type: LabelType, p: int, sx: float, sq: float, **_kwargs: Any):
+        super().__init__()
+        self._sx, self._sq = sx, sq
+
+
+class TransformUncertaintyLoss(DeepCLRLoss):
+    def __init__(self, label_type: LabelType, p: int, sx: float, sq: float, **_kwargs: Any):
+        super().__init__()
+        self._sx = torch.nn.Parameter(torch.Tensor([sx]))
+        self._sq = torch.nn.Parameter(torch.Tensor([sq]))
+
+    def get_weights(self) -> Dict:
+        return {'sx': self._sx.item(), 'sq': self._sq.item()}
+
+
+class AccumulatedLoss(DeepCLRLoss):
+    def __init__(self, modules: List[torch.nn.Module]):
+        super().__init__()
+        self.loss_list = torch.nn.ModuleList(modules)
+
+    def get_weights(self) -> Dict:
+        weights: Dict = {}
+        for loss in self.loss_list:
+            weights.update(loss.get_weights())
+        return weights
+
+
+def _init_loss(cfg: Config, label_type: LabelType, **kwargs: Any) -> DeepCLRLoss:
+    cls = _subclass_by_name(DeepCLRLoss, cfg['name'])
+    if cls is None:
+        raise NotImplementedError("Class '{}' not found as subclass of 'DeepCLRLoss'".format(cfg['name']))
+    return cls(label_type=label_type, **cfg['params'], **kwargs)
+
+
+# --------------------------------------------------------------------------------------------------
+# network
+# --------------------------------------------------------------------------------------------------
+class DeepCLR(BaseModel):
+    """Set abstraction over all 2B clouds -> flow embedding per pair -> pose head."""
+
+    def __init__(self, input_dim: int, label_type: LabelType, cloud_features: Config, merge: Config,
+                 output: Config, transform: Optional[Config] = None, loss: Optional[Any] = None, **kwargs: Any):
+        super().__init__()
+        if transform is not None:
+            raise NotImplementedError("no shipped model configures a transform layer")
+        self._input_dim = input_dim
+        cloud_features, merge, output = (Config.from_dict(c) if not isinstance(c, Config) else c
+                                         for c in (cloud_features, merge, output))
+        cloud = _init_module(cloud_features, input_dim=input_dim, **kwargs)
+        merge_layer = _init_module(merge, input_dim=cloud.output_dim(), **kwargs)
+        head = _init_module(output, input_dim=merge_layer.output_dim(), label_type=label_type, **kwargs)
+        self._cloud_layers = nn.Sequential(cloud)
+        self._merge_layers = nn.Sequential(merge_layer, head)
+        if loss is None:
+            self._loss_layer = None
+        elif isinstance(loss, list):
+            self._loss_layer = AccumulatedLoss([_init_loss(c, label_type, **kwargs) for c in loss])
+        else:
+            self._loss_layer = _init_loss(loss, label_type, **kwargs)
+
+    def get_input_dim(self) -> int:
+        return self._input_dim
+
+    def has_loss(self) -> bool:
+        return self._loss_layer is not None
+
+    def get_loss_weights(self) -> Dict:
+        return self._loss_layer.get_weights() if self._loss_layer is not None else {}
+
+    @property
+    def npoint(self) -> int:
+        return self._cloud_layers[0].npoint
+
+    # -- row-level pipeline (what bench.py and the sharded runner drive) ---------------------------
+    def cloud_feature_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """(2B, N, C) -> rows F ((2B)*npoint, 68)."""
+        return self._cloud_layers[0].forward_rows(x)
+
+    def merge_rows(self, f_rows: torch.Tensor, pairs: int) -> torch.Tensor:
+        e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
+        return self._merge_layers[1].forward_rows(e_rows, pairs)
+
+    @staticmethod
+    def _augment(x: torch.Tensor, m: torch.Tensor) -> None:
+        """In-place homogeneous transform of the point columns (reference: deepclr.py:512-514)."""
+        dim = m.shape[-1] - 1
+        pts = x[:, :, :dim]
+        x[:, :, :dim] = torch.baddbmm(m[:, :dim, dim].unsqueeze(1), pts, m[:, :dim, :dim].transpose(1, 2))
+
+    def cloud_features(self, x: torch.Tensor, m: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(2B, N, C) -> (2B, 3 + feat, npoint) in the reference's channel-major layout."""
+        if m is not None:
+            self._augment(x, m)
+        rows = self.cloud_feature_rows(x.contiguous())
+        return ops.rows_to_channels(rows, x.shape[0], self.npoint, self._cloud_layers[0].output_dim() - 3)
+
+    def forward(self, x: torch.Tensor, is_feat: bool = False, m: Optional[torch.Tensor] = None,
+                y: Optional[torch.Tensor] = None, debug: bool = False)\
+            -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Dict]]:
+        if y is not None and self._loss_layer is not None:
+            raise NotImplementedError("loss evaluation (training path) is outside the MI355X forward hot path")
+        if x.shape[0] % 2 != 0:
+            raise RuntimeError("batch must hold templates followed by the same number of sources")
+        pairs = x.shape[0] // 2
+        if is_feat:
+            f_rows = ops.channels_to_rows(x.contiguous(), ops.F_STRIDE)
+        else:
+            if m is not None:
+                self._augment(x, m)
+            f_rows = self.cloud_feature_rows(x.contiguous())
+        return self.merge_rows(f_rows, pairs), None, None

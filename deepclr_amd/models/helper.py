@@ -1,0 +1,130 @@
+"""Affine + ReLU stacks with the reference's parameter layout.
+
+Mirrors ``Conv1d`` / ``Linear`` / ``Conv1dMultiLayer`` / ``LinearMultiLayer``
+(/root/reference/deepclr/models/helper.py:11-123): xavier-uniform weights, zero
+bias, ReLU after EVERY layer including the last, and the nesting
+``_sequential.{i}._sequential.0.{weight,bias}`` that the shipped checkpoints use.
+Here the modules are parameter holders plus a forward that calls the MFMA GEMM
+(``dclr_linear``) or the small-row FC kernel (``dclr_fc``); they never run on CPU.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def _no_batch_norm(batch_norm: bool) -> None:
+    if batch_norm:
+        raise NotImplementedError("batch_norm=True is outside the MI355X hot path (every shipped "
+                                  "model_config.yaml sets batch_norm: false)")
+
+
+class Conv1d(nn.Module):
+    """1x1 convolution + ReLU over (B, C, N)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 1, bias: bool = True,
+                 batch_norm: bool = False):
+        super().__init__()
+        _no_batch_norm(batch_norm)
+        if kernel_size not in (1, (1,)):
+            raise NotImplementedError("only kernel_size 1 occurs on the hot path")
+        conv = nn.Conv1d(in_channels, out_channels, 1, bias=bias)
+        nn.init.xavier_uniform_(conv.weight)
+        if conv.bias is not None:
+            conv.bias.data.fill_(0.0)
+        self._sequential = nn.Sequential(conv)
+        self._output_dim = out_channels
+
+    def output_dim(self) -> int:
+        return self._output_dim
+
+    @property
+    def affine(self) -> nn.Conv1d:
+        return self._sequential[0]
+
+
+class Linear(nn.Module):
+    """Fully connected layer + ReLU over (B, C)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, batch_norm: bool = False):
+        super().__init__()
+        _no_batch_norm(batch_norm)
+        lin = nn.Linear(in_features, out_features, bias=bias)
+        nn.init.xavier_uniform_(lin.weight)
+        if bias:
+            lin.bias.data.fill_(0.0)
+        self._sequential = nn.Sequential(lin)
+        self._output_dim = out_features
+
+    def output_dim(self) -> int:
+        return self._output_dim
+
+    @property
+    def affine(self) -> nn.Linear:
+        return self._sequential[0]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.fc(x.contiguous(), self.affine.weight, self.affine.bias, act=1)
+
+
+class _Stack(nn.Module):
+    """Common layout of the two multi-layer containers. Dropout modules are kept as index
+    placeholders (state_dict keys depend on their positions); at inference they are the identity."""
+
+    def __init__(self, layer_cls, layer_sizes: List[int], batch_norm: bool, dropout_keep: float,
+                 dropout_last: bool, **layer_kwargs):
+        super().__init__()
+        mods: List[nn.Module] = []
+        pairs = list(zip(layer_sizes[:-1], layer_sizes[1:]))
+        for i, (c_in, c_out) in enumerate(pairs):
+            mods.append(layer_cls(c_in, c_out, bias=True, batch_norm=batch_norm, **layer_kwargs))
+            last = i == len(pairs) - 1
+            if dropout_keep < 1.0 and (not last or dropout_last):
+                mods.append(nn.Dropout(1.0 - dropout_keep))
+        self._sequential = nn.Sequential(*mods)
+        self._output_dim = layer_sizes[-1]
+
+    def output_dim(self) -> int:
+        return self._output_dim
+
+    def layers(self) -> List[nn.Module]:
+        return [m for m in self._sequential if not isinstance(m, nn.Dropout)]
+
+    def affine_params(self) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
+        return [(m.affine.weight, m.affine.bias) for m in self.layers()]
+
+
+class Conv1dMultiLayer(_Stack):
+    def __init__(self, layer_sizes: List[int], batch_norm: bool = False, dropout_keep: float = 1.0,
+                 dropout_last: bool = False):
+        super().__init__(Conv1d, layer_sizes, batch_norm, dropout_keep, dropout_last, kernel_size=1)
+
+
+class LinearMultiLayer(_Stack):
+    def __init__(self, layer_sizes: List[int], batch_norm: bool = False, dropout_keep: float = 1.0,
+                 dropout_last: bool = False):
+        super().__init__(Linear, layer_sizes, batch_norm, dropout_keep, dropout_last)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training and any(isinstance(m, nn.Dropout) for m in self._sequential):
+            raise NotImplementedError("dropout in training mode is outside the forward-only hot path")
+        for layer in self.layers():
+            x = layer(x)
+        return x
+
+
+class PackedCache:
+    """Re-derive kernel-side weight buffers only when a parameter changed (load_state_dict, .to())."""
+
+    def __init__(self):
+        self._key = None
+        self._value = None
+
+    def get(self, params, build):
+        key = tuple((p.device, p.data_ptr(), p._version) for p in params)
+        if key != self._key:
+            self._value = build()
+            self._key = key
+        return self._value

@@ -1,0 +1,218 @@
+"""Operator-level API: the functions the reference imports from its native extensions.
+
+Level 1 mirrors, name for name and argument for argument, what
+``deepclr/models/deepclr.py`` obtains from the absent third-party packages:
+``pointnet2`` (``furthest_point_sample``, ``gather_operation``, ``ball_query``,
+``grouping_operation``; exported by /root/reference/extern/pointnet2.patch:37-40) and
+``torch_cluster.knn`` (call site deepclr.py:164-166). Level 2 exposes the fused
+kernels the model forward uses. Everything runs on the current torch stream.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import lib
+
+F_STRIDE = 68
+E_STRIDE = 264
+
+
+# ------------------------------------------------------------------------------------------------
+# level 1
+# ------------------------------------------------------------------------------------------------
+def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    """xyz (B, N, 3) -> (B, npoint) int32 indices."""
+    xyz = lib.dev_f32(xyz, 'xyz')
+    b, n, c = xyz.shape
+    assert c == 3
+    idx = torch.empty(b, npoint, dtype=torch.int32, device=xyz.device)
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
+    lib.check(lib.load().dclr_furthest_point_sampling(b, n, npoint, xyz.data_ptr(), temp.data_ptr(),
+                                                      idx.data_ptr(), lib.stream_ptr()), 'furthest_point_sample')
+    return idx
+
+
+def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """features (B, C, N), idx (B, npoint) int32 -> (B, C, npoint)."""
+    features = lib.dev_f32(features, 'features')
+    b, c, n = features.shape
+    assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
+    npoint = idx.shape[1]
+    out = torch.empty(b, c, npoint, dtype=torch.float32, device=features.device)
+    lib.check(lib.load().dclr_gather_points(b, c, n, npoint, features.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                            lib.stream_ptr()), 'gather_operation')
+    return out
+
+
+def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    """xyz (B, N, 3), new_xyz (B, npoint, 3) -> (B, npoint, nsample) int32."""
+    xyz, new_xyz = lib.dev_f32(xyz, 'xyz'), lib.dev_f32(new_xyz, 'new_xyz')
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.zeros(b, m, nsample, dtype=torch.int32, device=xyz.device)
+    lib.check(lib.load().dclr_ball_query(b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+                                         idx.data_ptr(), lib.stream_ptr()), 'ball_query')
+    return idx
+
+
+def grouping_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """features (B, C, N), idx (B, npoint, nsample) int32 -> (B, C, npoint, nsample)."""
+    features = lib.dev_f32(features, 'features')
+    b, c, n = features.shape
+    assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
+    _, npoint, nsample = idx.shape
+    out = torch.empty(b, c, npoint, nsample, dtype=torch.float32, device=features.device)
+    lib.check(lib.load().dclr_group_points(b, c, n, npoint, nsample, features.data_ptr(), idx.data_ptr(),
+                                           out.data_ptr(), lib.stream_ptr()), 'grouping_operation')
+    return out
+
+
+def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor] = None,
+        batch_y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index]."""
+    x, y = lib.dev_f32(x, 'x'), lib.dev_f32(y, 'y')
+    if x.dim() != 2 or x.shape[1] != 3 or y.shape[1] != 3:
+        raise RuntimeError("knn: only 3-d points are supported")
+    b = 1
+    if batch_x is not None or batch_y is not None:
+        if batch_x is None or batch_y is None:
+            raise RuntimeError("knn: give both batch vectors or neither")
+        b = int(batch_x[-1].item()) + 1
+        if int(batch_y[-1].item()) + 1 != b:
+            raise RuntimeError("knn: batch_x and batch_y disagree on the batch size")
+    nx, ny = x.shape[0] // b, y.shape[0] // b
+    if nx * b != x.shape[0] or ny * b != y.shape[0]:
+        raise RuntimeError("knn: only equally sized batch items are supported")
+    if nx < k:
+        raise RuntimeError("knn: fewer candidates per batch item than k")
+    row = torch.empty(b * ny * k, dtype=torch.int64, device=x.device)
+    col = torch.empty(b * ny * k, dtype=torch.int64, device=x.device)
+    lib.check(lib.load().dclr_knn(b, nx, ny, k, x.data_ptr(), y.data_ptr(), row.data_ptr(), col.data_ptr(),
+                                  lib.stream_ptr()), 'knn')
+    return torch.stack((row, col), dim=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# level 2
+# ------------------------------------------------------------------------------------------------
+def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
+    """clouds (B, N, C>=3) interleaved -> (B, npoint) int32."""
+    clouds = lib.dev_f32(clouds, 'clouds')
+    b, n, c = clouds.shape
+    idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
+    lib.check(lib.load().dclr_fps_clouds(b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr()),
+              'fps_clouds')
+    return idx
+
+
+def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    """[W1 b1 W2 b2 W3 b3] flat f32 buffer for dclr_sa_msg_fused (1x1 conv weights (out,in,1,1))."""
+    parts = []
+    for w, bias in zip(weights, biases):
+        parts += [w.detach().reshape(w.shape[0], -1).reshape(-1), bias.detach().reshape(-1)]
+    return torch.cat(parts).to(torch.float32).contiguous()
+
+
+def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[float], nsamples: Sequence[int],
+                 mlps: List[torch.Tensor], want_counts: bool = False):
+    """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)]."""
+    clouds = lib.dev_f32(clouds, 'clouds')
+    b, n, c = clouds.shape
+    npoint = fps_idx.shape[1]
+    ns = len(radii)
+    out = torch.empty(b * npoint, F_STRIDE, dtype=torch.float32, device=clouds.device)
+    counts = torch.empty(b, npoint, ns, dtype=torch.int32, device=clouds.device) if want_counts else None
+    radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
+    nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
+    mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
+    lib.check(lib.load().dclr_sa_msg_fused(b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
+                                           ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
+                                           ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
+                                           lib.stream_ptr()), 'sa_msg_fused')
+    return (out, counts) if want_counts else out
+
+
+def _xyz_col(stride: int) -> int:
+    return {F_STRIDE: 64, E_STRIDE: 256}[stride]
+
+
+def rows_to_channels(rows: torch.Tensor, b: int, npoint: int, nfeat: int) -> torch.Tensor:
+    """rows F / E (b*npoint, stride) -> reference layout (b, 3 + nfeat, npoint) [xyz | first nfeat features]."""
+    rows = lib.dev_f32(rows, 'rows')
+    out = torch.empty(b, 3 + nfeat, npoint, dtype=torch.float32, device=rows.device)
+    lib.check(lib.load().dclr_rows_to_channels(b, npoint, nfeat, _xyz_col(rows.shape[1]), rows.shape[1],
+                                               rows.data_ptr(), out.data_ptr(), lib.stream_ptr()), 'rows_to_channels')
+    return out
+
+
+def channels_to_rows(channels: torch.Tensor, stride: int) -> torch.Tensor:
+    """reference layout (b, 3 + nfeat, npoint) -> rows (b*npoint, stride)."""
+    channels = lib.dev_f32(channels, 'channels')
+    b, ch, npoint = channels.shape
+    rows = torch.empty(b * npoint, stride, dtype=torch.float32, device=channels.device)
+    lib.check(lib.load().dclr_channels_to_rows(b, npoint, ch - 3, _xyz_col(stride), stride, channels.data_ptr(),
+                                               rows.data_ptr(), lib.stream_ptr()), 'channels_to_rows')
+    return rows
+
+
+def pack_weight(w: torch.Tensor, kp: int, kmap: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-major (n_out, k_in) -> MFMA fragment order, K padded to kp, N padded to a multiple of 32."""
+    w = lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w')
+    n_out, k_in = w.shape
+    np_ = (n_out + 31) // 32 * 32
+    packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)
+    if kmap is not None:
+        assert kmap.dtype == torch.int32 and kmap.numel() == kp and kmap.is_cuda
+    lib.check(lib.load().dclr_pack_weight(n_out, k_in, w.data_ptr(), lib.ptr(kmap), kp, np_, packed.data_ptr(),
+                                          lib.stream_ptr()), 'pack_weight')
+    return packed
+
+
+def linear(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], n: int, kp: int, relu: bool,
+           ldy: Optional[int] = None, colmax_groups: Optional[int] = None) -> torch.Tensor:
+    """rows x (m, ldx) -> rows y (m, ldy) = act(x[:, :kp] W^T + b), or, with colmax_groups = G,
+    the (G, n) column maxima over each block of m/G rows."""
+    x = lib.dev_f32(x, 'x')
+    m, ldx = x.shape
+    if colmax_groups is not None:
+        out = torch.zeros(colmax_groups, n, dtype=torch.float32, device=x.device)
+        lib.check(lib.load().dclr_linear(m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), 1, None, 0,
+                                         out.data_ptr(), m // colmax_groups, lib.stream_ptr()), 'linear(colmax)')
+        return out
+    ldy = n if ldy is None else ldy
+    alloc = torch.zeros if ldy > n else torch.empty     # padding columns feed the next layer's zero weights
+    y = alloc(m, ldy, dtype=torch.float32, device=x.device)
+    lib.check(lib.load().dclr_linear(m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), int(relu),
+                                     y.data_ptr(), ldy, None, 0, lib.stream_ptr()), 'linear')
+    return y
+
+
+def knn_rows(f_rows: torch.Tensor, pairs: int, npoint: int, k: int) -> torch.Tensor:
+    f_rows = lib.dev_f32(f_rows, 'f_rows')
+    idx = torch.empty(pairs, npoint, k, dtype=torch.int32, device=f_rows.device)
+    lib.check(lib.load().dclr_knn_rows(pairs, npoint, k, f_rows.data_ptr(), idx.data_ptr(), lib.stream_ptr()),
+              'knn_rows')
+    return idx
+
+
+def flow_embedding_fused(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.Tensor, ps: torch.Tensor,
+                         w1a: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+                         w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
+    pairs, npoint, k = knn_idx.shape
+    e = torch.empty(pairs * npoint, E_STRIDE, dtype=torch.float32, device=f_rows.device)
+    lib.check(lib.load().dclr_flow_embedding_fused(pairs, npoint, k, float(radius), f_rows.data_ptr(),
+                                                   knn_idx.data_ptr(), pt.data_ptr(), ps.data_ptr(), w1a.data_ptr(),
+                                                   b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3p.data_ptr(),
+                                                   b3.data_ptr(), e.data_ptr(), lib.stream_ptr()), 'flow_embedding')
+    return e
+
+
+def fc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    x, w = lib.dev_f32(x, 'x'), lib.dev_f32(w, 'w')
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    lib.check(lib.load().dclr_fc(m, n, k, x.data_ptr(), w.data_ptr(), lib.ptr(bias), act, y.data_ptr(),
+                                 lib.stream_ptr()), 'fc')
+    return y

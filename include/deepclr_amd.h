@@ -1,0 +1,163 @@
+/*
+ * deepclr_amd.h -- C ABI of libdeepclr_amd.so (gfx950 / MI355X).
+ *
+ * The library is the drop-in boundary for DeepCLR's forward hot path
+ * (BASELINE.json north_star). Conventions, all entry points:
+ *
+ *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory
+ *     unless its name ends in _host;
+ *   - the caller allocates every output and workspace; the library never
+ *     allocates, never synchronises and keeps no global state (re-entrant);
+ *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued
+ *     asynchronously on it, exactly like the reference's wrappers enqueue on
+ *     at::cuda::getCurrentCUDAStream() (/root/reference/extern/pointnet2.patch:113,155,285,317);
+ *   - return value: 0 = enqueued; DCLR_E_* < 0 = rejected before any launch;
+ *     -(1000 + hipError_t) = the HIP runtime refused the launch. The reference
+ *     wrappers return a constant 1 that callers ignore and signal misuse through
+ *     TORCH_CHECK -> RuntimeError (pointnet2.patch:97-99); the Python host layer
+ *     (deepclr_amd/lib.py) turns any non-zero code into RuntimeError likewise.
+ *
+ * Frozen distance recipe shared with the oracle (oracle/primitives.c):
+ *   d = (dx*dx + dy*dy) + dz*dz in binary32, one rounding per operation, no FMA.
+ */
+#ifndef DEEPCLR_AMD_H
+#define DEEPCLR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCLR_OK             0
+#define DCLR_E_INVALID     (-1)   /* NULL pointer, non-positive size, size relation violated */
+#define DCLR_E_UNSUPPORTED (-2)   /* valid request outside what the kernels are built for     */
+
+typedef void *dclr_stream_t;      /* hipStream_t */
+
+int         dclr_version(void);                 /* 1000*major + minor */
+const char *dclr_error_string(int code);        /* static string, never NULL */
+
+/* ------------------------------------------------------------------------------------------
+ * Level 1 -- operator-for-operator replacements of the reference's native extension
+ * `pointnet2_cuda` and of `torch_cluster.knn` (same argument order and meaning).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces furthest_point_sampling_wrapper(b, n, m, points, temp, idx)
+ * (/root/reference/extern/pointnet2.patch:306-320).
+ * points (b,n,3) f32; temp (b,n) f32 pre-filled by the caller (1e10); idx (b,m) i32.
+ * idx[.,0] = 0; temp holds the final running minimum distances on return. Any n >= 1, m >= 1
+ * (m > n keeps emitting index 0 once every point is taken). */
+int dclr_furthest_point_sampling(int b, int n, int m, const float *points, float *temp,
+                                 int32_t *idx, dclr_stream_t stream);
+
+/* Replaces gather_points_wrapper_fast(b, c, n, npoints, points, idx, out)
+ * (/root/reference/extern/pointnet2.patch:275-288).
+ * points (b,c,n) f32; idx (b,npoints) i32; out (b,c,npoints): out[b,c,j] = points[b,c,idx[b,j]]. */
+int dclr_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                       float *out, dclr_stream_t stream);
+
+/* Replaces ball_query_wrapper_fast(b, n, m, radius, nsample, new_xyz, xyz, idx)
+ * (/root/reference/extern/pointnet2.patch:101-116).
+ * new_xyz (b,m,3), xyz (b,n,3) f32; idx (b,m,nsample) i32, zero-filled by the caller.
+ * Per centroid: the first nsample point indices k (ascending) with d2 < radius*radius; unused
+ * slots repeat the first hit; a centroid with no hit leaves its row untouched. */
+int dclr_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                    const float *xyz, int32_t *idx, dclr_stream_t stream);
+
+/* Replaces group_points_wrapper_fast(b, c, n, npoints, nsample, points, idx, out)
+ * (/root/reference/extern/pointnet2.patch:160-174).
+ * points (b,c,n); idx (b,npoints,nsample); out (b,c,npoints,nsample) = points[b,c,idx[b,j,s]]. */
+int dclr_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                      const int32_t *idx, float *out, dclr_stream_t stream);
+
+/* Replaces torch_cluster.knn(x, y, k, batch_x, batch_y) for the equally sized, sorted batches
+ * DeepCLR builds (/root/reference/deepclr/models/deepclr.py:149-155,164-166).
+ * x (b*nx,3) candidates, y (b*ny,3) queries; row, col (b*ny*k) i64: row = global query index,
+ * col = global candidate index, each query's k entries contiguous, ascending distance, equal
+ * distances in ascending candidate index. Needs 1 <= k <= 64 and nx >= k. */
+int dclr_knn(int b, int nx, int ny, int k, const float *x, const float *y, int64_t *row,
+             int64_t *col, dclr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Level 2 -- the fused forward path. Internal activations are point-major rows:
+ *   cloud-feature rows  F (clouds*npoint, 68):  [feat 0..63 | x y z | 0]
+ *   flow-embedding rows E (pairs*npoint, 264):  [feat 0..255 | x y z | 0 x5]
+ * and MLP weights are pre-packed once into MFMA fragment order (dclr_pack_weight).
+ * ---------------------------------------------------------------------------------------- */
+
+#define DCLR_F_STRIDE 68
+#define DCLR_E_STRIDE 264
+
+/* FPS on interleaved clouds (b, n, c) f32, c in {3,4,...}: xyz = first 3 of each point. No temp
+ * buffer (running minima live in registers); idx (b,m) i32. Same result as
+ * dclr_furthest_point_sampling on the xyz slice with temp = 1e10. */
+int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *idx,
+                    dclr_stream_t stream);
+
+/* Set abstraction, multi-scale grouping, fused (reference: SetAbstraction.forward,
+ * /root/reference/deepclr/models/deepclr.py:88-94, -> PointnetSAModuleMSG with use_xyz=True, bn=False):
+ * per sampled centroid and scale: ball query -> [xyz - centroid, features] -> 1x1-conv MLP
+ * (c -> 16 -> 16 -> 32, ReLU each) -> max over the neighbourhood. Neighbourhoods are never
+ * materialised; slots that only repeat the first hit are skipped (max is idempotent).
+ * clouds (b,n,c), c in {3,4}; fps_idx (b,npoint); n_scales in {1,2}; radii_host/nsamples_host are
+ * HOST arrays read at call time; mlp[s] is a device array [W1(16,c) b1(16) W2(16,16) b2(16) W3(32,16) b3(32)];
+ * out rows F (b*npoint, 68), scale s at columns 32*s..; counts (b,npoint,n_scales) i32 or NULL
+ * receives min(hits, nsample) per centroid (diagnostics / parity tests). */
+int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx,
+                      int n_scales, const float *radii_host, const int *nsamples_host,
+                      const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
+                      dclr_stream_t stream);
+
+/* Layout conversion between rows F/E and the reference's channel-major tensors:
+ * channels (b, 3 + nfeat, npoint) with xyz in channels 0..2  <->  rows (b*npoint, stride) with the
+ * nfeat feature columns first and xyz at columns xyz_col..xyz_col+2 (64 for F, 256 for E); every
+ * other row column is written as zero by dclr_channels_to_rows. */
+int dclr_rows_to_channels(int b, int npoint, int nfeat, int xyz_col, int stride, const float *rows,
+                          float *channels, dclr_stream_t stream);
+int dclr_channels_to_rows(int b, int npoint, int nfeat, int xyz_col, int stride, const float *channels,
+                          float *rows, dclr_stream_t stream);
+
+/* Pack a row-major weight W (n_out, k_in) into MFMA fragment order for dclr_linear / the fused
+ * kernels. kmap (kp) i32 DEVICE array or NULL: packed K position -> source column (-1 = zero);
+ * NULL = identity, zero padded. kp = padded K (multiple of 8), np = padded N (multiple of 32);
+ * packed holds np*kp floats. */
+int dclr_pack_weight(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int np,
+                     float *packed, dclr_stream_t stream);
+
+/* Y = act(X * W^T + bias): X rows (m, ldx) using its first kp columns, packed W (np, kp), bias (n) or
+ * NULL, Y rows (m, ldy) first n columns. relu != 0 applies max(.,0). Requires m % 64 == 0,
+ * ldx % 4 == 0 and 16-byte aligned X. If colmax != NULL nothing is written to Y; instead
+ * colmax (m / rows_per_group, n) receives the per-group column maxima of the activated output
+ * through atomic max -- the caller zero-fills it, relu must be set, rows_per_group % 64 == 0. */
+int dclr_linear(int m, int n, int kp, const float *x, int ldx, const float *w_packed, const float *bias,
+                int relu, float *y, int ldy, float *colmax, int rows_per_group, dclr_stream_t stream);
+
+/* kNN on feature rows: queries = template clouds 0..pairs-1, candidates = source clouds
+ * pairs..2*pairs-1 of F (xyz at columns 64..66). knn_idx (pairs, npoint, k) i32 local candidate
+ * indices, ordered as dclr_knn orders them. */
+int dclr_knn_rows(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx,
+                  dclr_stream_t stream);
+
+/* Flow embedding, fused (reference: MotionEmbeddingBase.forward,
+ * /root/reference/deepclr/models/deepclr.py:201-231, append_features=True, 131->128->128->256):
+ * layer 1 is split as W1 = [W1a | W1b | W1c] over [pos_diff | template feat | source feat];
+ * pt/ps (pairs*npoint,128) hold W1b*feat_t and W1c*feat_s (dclr_linear, no bias, no relu).
+ * Per template point: gather its k neighbours, h1 = relu(pt + ps[nb] + W1a*pos_diff + b1),
+ * two MFMA layers, zero rows with |pos_diff| >= radius (radius <= 0 disables), max over k.
+ * w1a (128,3) row-major, b1 (128); w2p/w3p packed (128,128)/(256,128); out rows E. k <= 32. */
+int dclr_flow_embedding_fused(int pairs, int npoint, int k, float radius, const float *f_rows,
+                              const int32_t *knn_idx, const float *pt, const float *ps,
+                              const float *w1a, const float *b1, const float *w2p, const float *b2,
+                              const float *w3p, const float *b3, float *e_rows, dclr_stream_t stream);
+
+/* Fully connected tail on a handful of rows: y (m,n) = act(x (m,k) * w (n,k)^T + bias).
+ * act: 0 none, 1 relu, 2 dual-quaternion head (sigmoid on column 0, tanh on 1..3; reference
+ * OutputSimple._output_activation, deepclr.py:279-281), 3 quaternion head (sigmoid col 3, tanh 4..6). */
+int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act, float *y,
+            dclr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCLR_AMD_H */

@@ -1,0 +1,232 @@
+"""GPU parity, level 2: the fused forward path against the CPU oracle and the committed goldens.
+
+Tolerances: indices/counts exact; activations rtol 1e-4 / atol 1e-5 against fp32 CPU (the MFMA
+kernels are exact fp32 fmaf chains, only the summation order differs from the CPU GEMMs); pose
+4x4 within 1e-4 absolute (BASELINE.json's stated tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import labels as olabels
+from deepclr_amd import ops, synthetic
+from deepclr_amd.config import model_config_from_dict
+from deepclr_amd.labels import LabelType
+from deepclr_amd.models import build_model, ModelInferenceHelper
+from helpers import GOLDEN_CASES, load_golden, case_cfg, degenerate_batch, pose_delta
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _models(cfg: dict, sd):
+    model = build_model(model_config_from_dict(cfg))
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV).eval(), oracle.build_oracle_model(cfg, sd)
+
+
+def _mats(y):
+    return np.stack([LabelType.POSE3D_DUAL_QUAT.to_matrix(v) for v in y.detach().cpu().numpy()])
+
+
+def _close(got: torch.Tensor, want, rtol=RTOL, atol=ATOL):
+    want = torch.as_tensor(want)
+    scale = max(1.0, float(want.abs().max()))
+    torch.testing.assert_close(got.detach().cpu(), want, rtol=rtol, atol=atol * scale)
+
+
+@pytest.mark.parametrize('name', list(GOLDEN_CASES))
+def test_model_matches_golden_and_oracle(name):
+    g, cfg, sd = load_golden(name)
+    model, orc = _models(cfg, sd)
+    x = torch.from_numpy(g['x']).to(DEV)
+    with torch.no_grad():
+        feat = model.cloud_features(x.clone())
+        emb = model._merge_layers[0](feat)
+        y, loss, dbg = model(x.clone())
+        y_feat, _, _ = model(feat, is_feat=True)
+    assert loss is None and dbg is None
+    # stage by stage against the reference-composition golden
+    assert torch.equal(feat[:, :3, :].cpu(), torch.from_numpy(g['x'])[:, :, :3].gather(
+        1, torch.from_numpy(g['fps_idx'].astype(np.int64))[:, :, None].expand(-1, -1, 3)).transpose(1, 2))
+    if GOLDEN_CASES[name][1]:
+        _close(feat, g['cloud_features'])
+        _close(emb, g['flow_embedding'])
+    else:
+        for key, t in (('cloud_features', feat), ('flow_embedding', emb)):
+            assert tuple(t.shape) == tuple(g[key + '_shape'])
+            got = t.contiguous().view(-1)[torch.from_numpy(g[key + '_pos']).to(DEV)]
+            _close(got, g[key + '_val'])
+    _close(y, g['y'])
+    _close(y_feat, g['y'])
+    assert np.abs(_mats(y) - g['mat']).max() < 1e-4
+    # and against the oracle recomputed on this host
+    _close(y, orc(torch.from_numpy(g['x'])))
+
+
+@pytest.mark.parametrize('kind,n,pairs', [('kitti', 4096, 2), ('modelnet', 2048, 3)])
+def test_fused_stages_against_oracle(kind, n, pairs):
+    cfg = synthetic.model_cfg(kind)
+    sd = synthetic.random_state_dict(cfg, seed=21)
+    model, orc = _models(cfg, sd)
+    x_cpu = torch.from_numpy(synthetic.make_batch(kind, pairs, n, first_pair=40))
+    x = x_cpu.to(DEV)
+    sa = cfg['params']['cloud_features']['params']
+    npoint = sa['npoint'][0]
+
+    # sampling + grouping indices: exact
+    fps = ops.fps_clouds(x, npoint)
+    xyz = x_cpu[:, :, :3].contiguous()
+    fps_o = oracle.furthest_point_sample(xyz, npoint)
+    assert torch.equal(fps.cpu(), fps_o)
+    new_xyz = oracle.gather_operation(xyz.transpose(1, 2).contiguous(), fps_o).transpose(1, 2).contiguous()
+    sam = model._cloud_layers[0]._sa0
+    rows, counts = ops.sa_msg_fused(x, fps, sam.radii, sam.nsamples, sam.packed_mlps(), want_counts=True)
+    for s, (r, ns) in enumerate(zip(sam.radii, sam.nsamples)):
+        bq = oracle.ball_query(r, ns, xyz, new_xyz)
+        # hits = 1 + number of later slots that are not padding (padding repeats the first hit;
+        # every centroid is a cloud point, so it always hits itself)
+        hits = 1 + (bq[:, :, 1:] != bq[:, :, :1]).sum(-1)
+        assert torch.equal(counts[:, :, s].cpu(), hits.to(torch.int32)), 'scale %d' % s
+
+    feat_o = orc.cloud_features(x_cpu)
+    with torch.no_grad():
+        feat = model.cloud_features(x.clone())
+    _close(feat, feat_o)
+
+    # kNN on the oracle's features (identical xyz) : exact neighbour lists
+    f_rows = ops.channels_to_rows(feat_o.to(DEV).contiguous(), ops.F_STRIDE)
+    k = cfg['params']['merge']['params']['k']
+    knn_idx = ops.knn_rows(f_rows, pairs, npoint, k).cpu()
+    _, _, gi = orc.knn_groups(feat_o[:pairs], feat_o[pairs:])
+    local = (gi[1] - (torch.arange(pairs).repeat_interleave(npoint) * npoint).view(-1, 1)).view(pairs, npoint, k)
+    assert torch.equal(knn_idx.long(), local)
+
+    with torch.no_grad():
+        emb = model._merge_layers[0](feat_o.to(DEV))
+        emb_o = orc.flow_embedding(feat_o)
+        _close(emb, emb_o)
+        y = model._merge_layers[1](emb_o.to(DEV))
+        _close(y, orc.pose_head(emb_o))
+        y_full, _, _ = model(x.clone())
+    y_o = orc(x_cpu)
+    _close(y_full, y_o)
+    mats_o = np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])
+    assert pose_delta(_mats(y_full), mats_o) < 1e-4
+
+
+def test_radius_mask_is_exercised():
+    """ModelNet arch: flow-embedding radius 0.2 with k = 30 of 512 points masks many neighbours."""
+    cfg = synthetic.model_cfg('modelnet')
+    sd = synthetic.random_state_dict(cfg, seed=3)
+    model, orc = _models(cfg, sd)
+    x_cpu = torch.from_numpy(synthetic.make_batch('modelnet', 1, 1024, first_pair=7))
+    feat_o = orc.cloud_features(x_cpu)
+    pts0, pts1, gi = orc.knn_groups(feat_o[:1], feat_o[1:])
+    d = (pts1[gi[1]][:, :, :3] - pts0[gi[0]][:, :, :3]).norm(dim=2)
+    frac = (d >= 0.2).float().mean().item()
+    assert 0.05 < frac < 0.95, frac
+    with torch.no_grad():
+        _close(model._merge_layers[0](feat_o.to(DEV)), orc.flow_embedding(feat_o))
+
+
+def test_degenerate_inputs():
+    """Duplicates (exact ties everywhere) and npoint > N (reference test's 96-point clouds)."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=8)
+    model, orc = _models(cfg, sd)
+    x_cpu = torch.from_numpy(degenerate_batch(2, 96, 4, 77))
+    with torch.no_grad():
+        y, _, _ = model(x_cpu.to(DEV))
+    _close(y, orc(x_cpu))
+
+
+def test_reference_layer_shapes():
+    """Shapes asserted by /root/reference/tests/model/test_deepclr.py:19-57 (5 pairs x 96 points)."""
+    from deepclr_amd.models.deepclr import SetAbstraction, MotionEmbedding, OutputSimple
+    cfg = model_config_from_dict(synthetic.model_cfg('kitti'))
+    clouds_internal = torch.rand(10, cfg.input_dim, 96, device=DEV)
+    sa = SetAbstraction(input_dim=cfg.input_dim, point_dim=cfg.point_dim, **cfg.params.cloud_features.params).to(DEV)
+    f = sa(clouds_internal)
+    assert f.shape == (10, 67, 1024)
+    me = MotionEmbedding(input_dim=sa.output_dim(), point_dim=cfg.point_dim, **cfg.params.merge.params).to(DEV)
+    e = me(f)
+    assert e.shape == (5, 259, 1024)
+    head = OutputSimple(input_dim=me.output_dim(), label_type=cfg.label_type, **cfg.params.output.params).to(DEV)
+    assert head(e).shape == (5, cfg.label_type.dim)
+    model = build_model(cfg).to(DEV)
+    clouds = torch.rand(10, 96, cfg.input_dim, device=DEV)
+    with torch.no_grad():
+        y1, _, _ = model(clouds)
+        y2, _, _ = model(model.cloud_features(clouds), is_feat=True)
+    assert y1.shape == y2.shape == (5, 8)
+    assert torch.equal(y1, y2)
+
+
+def test_inference_helper_pairwise_and_sequential():
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=4)
+    model, orc = _models(cfg, sd)
+    frames = [torch.from_numpy(synthetic.kitti_like_pair(i, 2048)[0]) for i in range(3)]
+    pair = ModelInferenceHelper(model, is_sequential=False)
+    seq = ModelInferenceHelper(model, is_sequential=True)
+    assert seq.predict(frames[0].to(DEV)) is None and seq.has_state()
+    for a, b in ((0, 1), (1, 2)):
+        want = orc(torch.stack((frames[a], frames[b])))[0]
+        _close(pair.predict(frames[b].to(DEV), frames[a].to(DEV)), want)
+        _close(seq.predict(frames[b].to(DEV)), want)
+    seq.reset_state()
+    assert not seq.has_state()
+    with pytest.raises(RuntimeError):
+        pair.predict(frames[0].to(DEV))
+    with pytest.raises(RuntimeError):
+        pair.predict(frames[0][:, :3].to(DEV), frames[1].to(DEV))
+    with pytest.warns(UserWarning):
+        wide = torch.cat((frames[0], frames[0][:, :1]), dim=1).to(DEV)
+        pair.predict(wide, frames[1].to(DEV))
+    batch = pair.predict_batch(torch.stack(frames[1:]).to(DEV), torch.stack(frames[:2]).to(DEV))
+    _close(batch[1], orc(torch.stack((frames[1], frames[2])))[0])
+
+
+def test_linear_kernel_against_torch():
+    rng = np.random.default_rng(0)
+    for m, n, k in ((64, 32, 8), (128, 100, 259), (256, 256, 512), (192, 1024, 64)):
+        kp = (k + 7) // 8 * 8
+        x = torch.zeros(m, kp + 4)
+        x[:, :k] = torch.from_numpy(rng.normal(size=(m, k)).astype(np.float32))
+        w = torch.from_numpy(rng.normal(size=(n, k)).astype(np.float32)) / np.sqrt(k)
+        b = torch.from_numpy(rng.normal(size=(n,)).astype(np.float32))
+        wp = ops.pack_weight(w.to(DEV), kp)
+        want = torch.relu(x[:, :k].double() @ w.double().T + b.double()).float()
+        _close(ops.linear(x.to(DEV), wp, b.to(DEV), n, kp, relu=True), want)
+        groups = m // 64
+        _close(ops.linear(x.to(DEV), wp, b.to(DEV), n, kp, relu=True, colmax_groups=groups),
+               want.view(groups, 64, n).max(dim=1).values)
+        raw = (x[:, :k].double() @ w.double().T).float()
+        _close(ops.linear(x.to(DEV), wp, None, n, kp, relu=False), raw)
+
+
+def test_full_size_kitti_batch_properties_and_oracle_pair():
+    """BASELINE.json config 2 (B=8, N=16384): properties on the whole batch, oracle parity on pair 0."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=0)
+    model, orc = _models(cfg, sd)
+    x_np = synthetic.make_batch('kitti', 8, 16384)
+    x = torch.from_numpy(x_np).to(DEV)
+    fps = ops.fps_clouds(x, 1024).long()
+    assert (fps[:, 0] == 0).all()
+    assert all(len(set(row.tolist())) == 1024 for row in fps.cpu())           # no point sampled twice
+    # greedy invariant: the distance of each new sample to the already chosen set never increases
+    pts = torch.gather(x[:, :, :3], 1, fps[:, :, None].expand(-1, -1, 3)).double()
+    d = torch.cdist(pts, pts)
+    mask = torch.tril(torch.ones(1024, 1024, dtype=torch.bool, device=DEV), diagonal=-1)
+    reach = torch.where(mask, d, torch.full_like(d, float('inf'))).min(dim=2).values[:, 1:]
+    assert (reach[:, 1:] <= reach[:, :-1] + 1e-9).all()
+    with torch.no_grad():
+        y, _, _ = model(x.clone())
+        y_single, _, _ = model(x[[0, 8]].clone())
+    assert torch.equal(y[0], y_single[0])                                     # pairs are independent
+    y_o = orc(torch.from_numpy(x_np[[0, 8]]))
+    _close(y[:1], y_o)
+    assert pose_delta(_mats(y[:1]), np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])) < 1e-4

@@ -1,0 +1,110 @@
+"""GPU parity, level 1: every operator of the C ABI against the CPU oracle, bit for bit.
+
+Integer/index results must be identical (fixed seeds, tie-heavy inputs included); float
+gathers must be identical too (pure copies)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from deepclr_amd import ops, synthetic
+from helpers import degenerate_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _cloud(kind, b, n, seed):
+    rng = np.random.default_rng(seed)
+    if kind == 'normal':
+        x = rng.normal(size=(b, n, 3)).astype(np.float32)
+    elif kind == 'kitti':
+        x = synthetic.make_batch('kitti', (b + 1) // 2, n, first_pair=seed)[:b, :, :3]
+    elif kind == 'dup':                       # duplicates force exact distance ties
+        x = degenerate_batch((b + 1) // 2, n, 3, seed)[:b]
+    elif kind == 'grid':                      # lattice: many equal distances between distinct points
+        x = rng.integers(0, 6, size=(b, n, 3)).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.mark.parametrize('kind,b,n,m', [
+    ('normal', 2, 1, 4), ('normal', 3, 37, 20), ('dup', 2, 96, 200), ('grid', 2, 300, 128),
+    ('normal', 2, 1000, 256), ('kitti', 2, 1024, 512), ('dup', 2, 1500, 512), ('grid', 2, 2048, 300),
+    ('kitti', 2, 4096, 1024), ('normal', 2, 5000, 700), ('kitti', 3, 16384, 1024), ('dup', 2, 12000, 512),
+    ('normal', 1, 20000, 200), ('kitti', 1, 65536, 150), ('grid', 1, 40000, 100),
+])
+def test_fps_bit_exact(kind, b, n, m):
+    xyz = _cloud(kind, b, n, seed=n + m)
+    want = oracle.furthest_point_sample(xyz, m)
+    got = ops.furthest_point_sample(xyz.to(DEV), m).cpu()
+    assert torch.equal(got, want), 'first mismatch at {}'.format((got != want).nonzero()[:3].tolist())
+
+
+def test_fps_level1_large_cloud_and_temp_side_effect():
+    """n > 65536 takes the global-temp kernel; temp must hold the final running minima."""
+    from deepclr_amd import lib
+    xyz = _cloud('normal', 1, 70000, 5)
+    m = 48
+    want = oracle.furthest_point_sample(xyz, m)
+    x = xyz.to(DEV)
+    for n_use in (70000, 3000):
+        xs = x[:, :n_use].contiguous()
+        temp = torch.full((1, n_use), 1e10, device=DEV)
+        idx = torch.empty(1, m, dtype=torch.int32, device=DEV)
+        lib.check(lib.load().dclr_furthest_point_sampling(1, n_use, m, xs.data_ptr(), temp.data_ptr(), idx.data_ptr(),
+                                                          lib.stream_ptr()), 'fps')
+        ref_idx = want if n_use == 70000 else oracle.furthest_point_sample(xyz[:, :n_use].contiguous(), m)
+        assert torch.equal(idx.cpu(), ref_idx)
+        sel = xs[0, idx[0, :-1].long()]                              # temp = min distance to the first m-1 picks
+        ref_temp = ((xs[0, :, None, :] - sel[None]) ** 2).sum(-1).min(dim=1).values
+        torch.testing.assert_close(temp[0], ref_temp, rtol=1e-5, atol=1e-6)
+
+
+def test_fps_clouds_matches_level1_on_interleaved_input():
+    x = torch.from_numpy(synthetic.make_batch('kitti', 1, 3000)).to(DEV)       # (2, 3000, 4)
+    a = ops.fps_clouds(x, 333)
+    b = ops.furthest_point_sample(x[:, :, :3].contiguous(), 333)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('kind,b,n,m,radius,nsample', [
+    ('kitti', 2, 2048, 256, 1.0, 32), ('kitti', 2, 16384, 1024, 0.5, 512), ('dup', 2, 96, 50, 0.3, 16),
+    ('grid', 1, 500, 100, 1.0, 8), ('normal', 2, 777, 130, 0.05, 4), ('normal', 1, 4096, 64, 10.0, 1024),
+])
+def test_ball_query_gather_group_bit_exact(kind, b, n, m, radius, nsample):
+    xyz = _cloud(kind, b, n, seed=n)
+    fps = oracle.furthest_point_sample(xyz, m)
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    new_xyz_o = oracle.gather_operation(xyz_t, fps)
+    new_xyz_g = ops.gather_operation(xyz_t.to(DEV), fps.to(DEV))
+    assert torch.equal(new_xyz_g.cpu(), new_xyz_o)
+    new_xyz = new_xyz_o.transpose(1, 2).contiguous()
+    if kind == 'normal' and radius < 0.1:
+        new_xyz[0, 0] = 100.0                                       # a centroid with no point in range
+    want = oracle.ball_query(radius, nsample, xyz, new_xyz)
+    got = ops.ball_query(radius, nsample, xyz.to(DEV), new_xyz.to(DEV))
+    assert torch.equal(got.cpu(), want)
+    feats = torch.from_numpy(np.random.default_rng(1).normal(size=(b, 5, n)).astype(np.float32))
+    assert torch.equal(ops.grouping_operation(feats.to(DEV), got).cpu(), oracle.grouping_operation(feats, want))
+
+
+@pytest.mark.parametrize('kind,b,nx,ny,k', [
+    ('normal', 2, 64, 64, 5), ('kitti', 2, 1024, 1024, 20), ('dup', 2, 512, 512, 30), ('grid', 2, 300, 200, 16),
+    ('normal', 1, 3000, 100, 64), ('normal', 3, 100, 257, 7),
+])
+def test_knn_bit_exact(kind, b, nx, ny, k):
+    x = _cloud(kind, b, nx, seed=1).reshape(-1, 3)
+    y = _cloud(kind, b, ny, seed=2).reshape(-1, 3)
+    bx, by = torch.arange(b).repeat_interleave(nx), torch.arange(b).repeat_interleave(ny)
+    want = oracle.knn(x, y, k, bx, by)
+    got = ops.knn(x.to(DEV), y.to(DEV), k, bx.to(DEV), by.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+def test_ops_reject_cpu_tensors_and_bad_sizes():
+    with pytest.raises(RuntimeError):
+        ops.furthest_point_sample(torch.zeros(1, 8, 3), 4)
+    with pytest.raises(RuntimeError):
+        ops.knn(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), 8)     # fewer candidates than k
+    with pytest.raises(RuntimeError):
+        ops.ball_query(0.1, 4, torch.zeros(1, 8, 3, device=DEV).transpose(1, 2), torch.zeros(1, 2, 3, device=DEV))
