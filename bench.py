@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Throughput of the DeepCLR forward hot path on MI355X: scan-pairs/s (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one forward pass of the whole hot path (FPS -> set abstraction -> kNN -> flow embedding ->
+pose head) over one batch of synthetic KITTI-sized pairs already resident in HBM: BASELINE.json
+configs[1], 8 pairs of 2 x 16384 points per GPU. Ranks own independent pairs (weak scaling, no
+data-path collective); the only exchange is an RCCL all-gather of the (8, 8) pose outputs per step.
+Rank 0 prints ONE JSON line. The CPU oracle is used only for the `cpu_baseline` leg and the pose
+check -- never inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deepclr_amd import ops, synthetic                      # noqa: E402
+from deepclr_amd.config import model_config_from_dict       # noqa: E402
+from deepclr_amd.labels import LabelType                    # noqa: E402
+from deepclr_amd.models import build_model                  # noqa: E402
+
+PAIRS_PER_GPU = 8
+POINTS = 16384
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+class LaunchTimer:
+    """HIP events around every library launch, on the stream the kernel is enqueued on."""
+
+    def __init__(self):
+        self.spans = []
+
+    def begin(self, name):
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+        return (name, start)
+
+    def end(self, token):
+        stop = torch.cuda.Event(enable_timing=True)
+        stop.record()
+        self.spans.append((token[0], token[1], stop))
+
+    def summary(self):
+        acc = {}
+        for name, a, b in self.spans:
+            tot, cnt = acc.get(name, (0.0, 0))
+            acc[name] = (tot + a.elapsed_time(b), cnt + 1)
+        return {k: {'total_ms': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1]} for k, v in acc.items()}
+
+
+def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int):
+    """(bound, units) per launch: flops for the MFMA kernels, bytes for the memory-shaped ones.
+    Figures are stated per scan pair in DESIGN.md section 'Kernels and rooflines'."""
+    sa = cfg['params']['cloud_features']['params']
+    npoint, k = sa['npoint'][0], cfg['params']['merge']['params']['k']
+    c = cfg['input_dim']
+    if name.startswith('linear'):
+        m, n, kk = (int(v) for v in name[name.index('[') + 1:-1].split('x'))
+        return 'mfma', 2.0 * m * n * kk
+    if name == 'flow_embedding':
+        rows = pairs * npoint * k
+        return 'mfma', 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5
+    if name == 'fps_clouds':        # reads every cloud once, writes the indices
+        return 'hbm', 2.0 * pairs * (n_points * c * 4 + npoint * 4)
+    if name == 'sa_msg_fused':      # reads every cloud once + index list, writes 68-float rows
+        return 'hbm', 2.0 * pairs * (n_points * c * 4 + npoint * 4 + npoint * 68 * 4)
+    if name == 'knn_rows':
+        return 'hbm', pairs * npoint * (2 * 68 * 4 + k * 4)
+    return 'hbm', 0.0
+
+
+def cpu_baseline(cfg, sd, budget_s: float = 15.0):
+    """The oracle (a port: the reference has no CPU path) on this host's cores."""
+    import oracle
+    orc = oracle.build_oracle_model(cfg, sd)
+    # a 1-GPU box grants a 16-core share of the host (more threads only oversubscribe it)
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(threads)
+    oracle.primitives.set_threads(threads)
+    x = torch.from_numpy(synthetic.make_batch('kitti', 1, POINTS))
+    orc(x)                                           # warm-up (library init, allocator)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc(torch.from_numpy(synthetic.make_batch('kitti', 1, POINTS, first_pair=done + 1)))
+        done += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed > budget_s or done >= 64:
+            break
+    return {'value': done / elapsed, 'unit': 'scan-pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': '{} pairs of 2x{} points, batch 1, fp32, {:.1f} s wall; torch intra-op + OpenMP threads = {}'
+                      .format(done, POINTS, elapsed, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-launch-timer', action='store_true', help='skip per-kernel HIP events (roofline = null)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={} (launch N>1 through torch.distributed.run)'
+                         .format(args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
+
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=0)
+    model = build_model(model_config_from_dict(cfg))
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    x = torch.from_numpy(synthetic.make_batch('kitti', PAIRS_PER_GPU, POINTS, first_pair=rank * PAIRS_PER_GPU)).to(dev)
+    gathered = torch.empty(world * PAIRS_PER_GPU, 8, device=dev) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            y, _, _ = model(x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y)
+            return gathered
+        return y
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        y = step()
+    timer = None if args.no_launch_timer else LaunchTimer()
+    ops.TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        pairs_total = world * PAIRS_PER_GPU * args.steps
+        roofline, kernels = None, None
+        if timer is not None:
+            kernels = timer.summary()
+            name = max(kernels, key=lambda k: kernels[k]['total_ms'])
+            bound, units = algorithmic_work(name, cfg, PAIRS_PER_GPU, POINTS)
+            sec = kernels[name]['avg_us'] * 1e-6
+            if bound == 'mfma':
+                achieved, peak, unit = units / sec / 1e12, FP32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
+            else:
+                achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
+            roofline = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
+                        'frac': achieved / peak, 'traffic': None, 'avg_us': kernels[name]['avg_us'],
+                        'share_of_step': kernels[name]['total_ms'] / (elapsed * 1e3)}
+        # pose check of the last step's first pair against the oracle (outside the timed region)
+        result = {
+            'metric': 'scan-pairs/sec (2x16384 pts)', 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'KITTI-sized scan pairs, 2x16384 pts x 4 ch, {} pairs/GPU/step '
+                                   '(BASELINE.json configs[1]); kitti_00-06 architecture, seeded random weights'
+                                   .format(PAIRS_PER_GPU),
+                       'pairs_per_gpu': PAIRS_PER_GPU, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world},
+            'roofline': roofline,
+        }
+        if kernels is not None:
+            result['kernels_us'] = {k: round(v['avg_us'], 1) for k, v in sorted(kernels.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            from oracle import labels as olabels
+            y_ref = oracle.build_oracle_model(cfg, sd)(x[[0, PAIRS_PER_GPU]].cpu())
+            lt = LabelType.POSE3D_DUAL_QUAT
+            result['pose_delta_vs_oracle'] = float(np.abs(lt.to_matrix(y[0].cpu().numpy())
+                                                          - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max())
+            result['cpu_baseline'] = cpu_baseline(cfg, sd)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -17,6 +17,21 @@ from . import lib
 F_STRIDE = 68
 E_STRIDE = 264
 
+# Optional launch timer (bench.py): an object with begin(name) -> token and end(token), called on the
+# stream the kernel is enqueued on. None in normal operation.
+TIMER = None
+
+
+def _call(name: str, what: str, *args) -> None:
+    fn = getattr(lib.load(), name)
+    if TIMER is None:
+        lib.check(fn(*args), what)
+        return
+    token = TIMER.begin(what)
+    code = fn(*args)
+    TIMER.end(token)
+    lib.check(code, what)
+
 
 # ------------------------------------------------------------------------------------------------
 # level 1
@@ -28,8 +43,8 @@ def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     assert c == 3
     idx = torch.empty(b, npoint, dtype=torch.int32, device=xyz.device)
     temp = torch.full((b, n), 1e10, dtype=torch.float32, device=xyz.device)
-    lib.check(lib.load().dclr_furthest_point_sampling(b, n, npoint, xyz.data_ptr(), temp.data_ptr(),
-                                                      idx.data_ptr(), lib.stream_ptr()), 'furthest_point_sample')
+    _call('dclr_furthest_point_sampling', 'furthest_point_sample', b, n, npoint, xyz.data_ptr(), temp.data_ptr(),
+                                                      idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -40,8 +55,8 @@ def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
     npoint = idx.shape[1]
     out = torch.empty(b, c, npoint, dtype=torch.float32, device=features.device)
-    lib.check(lib.load().dclr_gather_points(b, c, n, npoint, features.data_ptr(), idx.data_ptr(), out.data_ptr(),
-                                            lib.stream_ptr()), 'gather_operation')
+    _call('dclr_gather_points', 'gather_operation', b, c, n, npoint, features.data_ptr(), idx.data_ptr(), out.data_ptr(),
+                                            lib.stream_ptr())
     return out
 
 
@@ -51,8 +66,8 @@ def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Te
     b, n, _ = xyz.shape
     m = new_xyz.shape[1]
     idx = torch.zeros(b, m, nsample, dtype=torch.int32, device=xyz.device)
-    lib.check(lib.load().dclr_ball_query(b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
-                                         idx.data_ptr(), lib.stream_ptr()), 'ball_query')
+    _call('dclr_ball_query', 'ball_query', b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+                                         idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -63,8 +78,8 @@ def grouping_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tenso
     assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous()
     _, npoint, nsample = idx.shape
     out = torch.empty(b, c, npoint, nsample, dtype=torch.float32, device=features.device)
-    lib.check(lib.load().dclr_group_points(b, c, n, npoint, nsample, features.data_ptr(), idx.data_ptr(),
-                                           out.data_ptr(), lib.stream_ptr()), 'grouping_operation')
+    _call('dclr_group_points', 'grouping_operation', b, c, n, npoint, nsample, features.data_ptr(), idx.data_ptr(),
+                                           out.data_ptr(), lib.stream_ptr())
     return out
 
 
@@ -88,8 +103,8 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor
         raise RuntimeError("knn: fewer candidates per batch item than k")
     row = torch.empty(b * ny * k, dtype=torch.int64, device=x.device)
     col = torch.empty(b * ny * k, dtype=torch.int64, device=x.device)
-    lib.check(lib.load().dclr_knn(b, nx, ny, k, x.data_ptr(), y.data_ptr(), row.data_ptr(), col.data_ptr(),
-                                  lib.stream_ptr()), 'knn')
+    _call('dclr_knn', 'knn', b, nx, ny, k, x.data_ptr(), y.data_ptr(), row.data_ptr(), col.data_ptr(),
+                                  lib.stream_ptr())
     return torch.stack((row, col), dim=0)
 
 
@@ -101,8 +116,7 @@ def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
-    lib.check(lib.load().dclr_fps_clouds(b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr()),
-              'fps_clouds')
+    _call('dclr_fps_clouds', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -126,10 +140,10 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
-    lib.check(lib.load().dclr_sa_msg_fused(b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
+    _call('dclr_sa_msg_fused', 'sa_msg_fused', b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
                                            ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
                                            ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
-                                           lib.stream_ptr()), 'sa_msg_fused')
+                                           lib.stream_ptr())
     return (out, counts) if want_counts else out
 
 
@@ -141,8 +155,8 @@ def rows_to_channels(rows: torch.Tensor, b: int, npoint: int, nfeat: int) -> tor
     """rows F / E (b*npoint, stride) -> reference layout (b, 3 + nfeat, npoint) [xyz | first nfeat features]."""
     rows = lib.dev_f32(rows, 'rows')
     out = torch.empty(b, 3 + nfeat, npoint, dtype=torch.float32, device=rows.device)
-    lib.check(lib.load().dclr_rows_to_channels(b, npoint, nfeat, _xyz_col(rows.shape[1]), rows.shape[1],
-                                               rows.data_ptr(), out.data_ptr(), lib.stream_ptr()), 'rows_to_channels')
+    _call('dclr_rows_to_channels', 'rows_to_channels', b, npoint, nfeat, _xyz_col(rows.shape[1]), rows.shape[1],
+                                               rows.data_ptr(), out.data_ptr(), lib.stream_ptr())
     return out
 
 
@@ -151,8 +165,8 @@ def channels_to_rows(channels: torch.Tensor, stride: int) -> torch.Tensor:
     channels = lib.dev_f32(channels, 'channels')
     b, ch, npoint = channels.shape
     rows = torch.empty(b * npoint, stride, dtype=torch.float32, device=channels.device)
-    lib.check(lib.load().dclr_channels_to_rows(b, npoint, ch - 3, _xyz_col(stride), stride, channels.data_ptr(),
-                                               rows.data_ptr(), lib.stream_ptr()), 'channels_to_rows')
+    _call('dclr_channels_to_rows', 'channels_to_rows', b, npoint, ch - 3, _xyz_col(stride), stride, channels.data_ptr(),
+                                               rows.data_ptr(), lib.stream_ptr())
     return rows
 
 
@@ -164,8 +178,8 @@ def pack_weight(w: torch.Tensor, kp: int, kmap: Optional[torch.Tensor] = None) -
     packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)
     if kmap is not None:
         assert kmap.dtype == torch.int32 and kmap.numel() == kp and kmap.is_cuda
-    lib.check(lib.load().dclr_pack_weight(n_out, k_in, w.data_ptr(), lib.ptr(kmap), kp, np_, packed.data_ptr(),
-                                          lib.stream_ptr()), 'pack_weight')
+    _call('dclr_pack_weight', 'pack_weight', n_out, k_in, w.data_ptr(), lib.ptr(kmap), kp, np_, packed.data_ptr(),
+                                          lib.stream_ptr())
     return packed
 
 
@@ -177,22 +191,21 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     m, ldx = x.shape
     if colmax_groups is not None:
         out = torch.zeros(colmax_groups, n, dtype=torch.float32, device=x.device)
-        lib.check(lib.load().dclr_linear(m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), 1, None, 0,
-                                         out.data_ptr(), m // colmax_groups, lib.stream_ptr()), 'linear(colmax)')
+        _call('dclr_linear', 'linear+colmax[%dx%dx%d]' % (m, n, kp), m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), 1, None, 0,
+                                         out.data_ptr(), m // colmax_groups, lib.stream_ptr())
         return out
     ldy = n if ldy is None else ldy
     alloc = torch.zeros if ldy > n else torch.empty     # padding columns feed the next layer's zero weights
     y = alloc(m, ldy, dtype=torch.float32, device=x.device)
-    lib.check(lib.load().dclr_linear(m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), int(relu),
-                                     y.data_ptr(), ldy, None, 0, lib.stream_ptr()), 'linear')
+    _call('dclr_linear', 'linear[%dx%dx%d]' % (m, n, kp), m, n, kp, x.data_ptr(), ldx, w_packed.data_ptr(), lib.ptr(bias), int(relu),
+                                     y.data_ptr(), ldy, None, 0, lib.stream_ptr())
     return y
 
 
 def knn_rows(f_rows: torch.Tensor, pairs: int, npoint: int, k: int) -> torch.Tensor:
     f_rows = lib.dev_f32(f_rows, 'f_rows')
     idx = torch.empty(pairs, npoint, k, dtype=torch.int32, device=f_rows.device)
-    lib.check(lib.load().dclr_knn_rows(pairs, npoint, k, f_rows.data_ptr(), idx.data_ptr(), lib.stream_ptr()),
-              'knn_rows')
+    _call('dclr_knn_rows', 'knn_rows', pairs, npoint, k, f_rows.data_ptr(), idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -201,10 +214,10 @@ def flow_embedding_fused(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.
                          w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
     pairs, npoint, k = knn_idx.shape
     e = torch.empty(pairs * npoint, E_STRIDE, dtype=torch.float32, device=f_rows.device)
-    lib.check(lib.load().dclr_flow_embedding_fused(pairs, npoint, k, float(radius), f_rows.data_ptr(),
+    _call('dclr_flow_embedding_fused', 'flow_embedding', pairs, npoint, k, float(radius), f_rows.data_ptr(),
                                                    knn_idx.data_ptr(), pt.data_ptr(), ps.data_ptr(), w1a.data_ptr(),
                                                    b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3p.data_ptr(),
-                                                   b3.data_ptr(), e.data_ptr(), lib.stream_ptr()), 'flow_embedding')
+                                                   b3.data_ptr(), e.data_ptr(), lib.stream_ptr())
     return e
 
 
@@ -213,6 +226,6 @@ def fc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int)
     m, k = x.shape
     n = w.shape[0]
     y = torch.empty(m, n, dtype=torch.float32, device=x.device)
-    lib.check(lib.load().dclr_fc(m, n, k, x.data_ptr(), w.data_ptr(), lib.ptr(bias), act, y.data_ptr(),
-                                 lib.stream_ptr()), 'fc')
+    _call('dclr_fc', 'fc', m, n, k, x.data_ptr(), w.data_ptr(), lib.ptr(bias), act, y.data_ptr(),
+                                 lib.stream_ptr())
     return y

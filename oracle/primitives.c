@@ -197,6 +197,14 @@ void dclr_oracle_knn(int b, int nx, int ny, int k, const float *x, const float *
     }
 }
 
+void dclr_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int dclr_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

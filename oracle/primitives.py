@@ -40,6 +40,8 @@ def _load():
         lib.dclr_oracle_fps_block.argtypes = [i]
         lib.dclr_oracle_fps_block.restype = i
         lib.dclr_oracle_num_threads.restype = i
+        lib.dclr_oracle_set_threads.argtypes = [i]
+        lib.dclr_oracle_set_threads.restype = None
         for name in ('dclr_oracle_fps', 'dclr_oracle_gather_points', 'dclr_oracle_ball_query',
                      'dclr_oracle_group_points', 'dclr_oracle_knn'):
             getattr(lib, name).restype = None
@@ -54,6 +56,10 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 def num_threads() -> int:
     return int(_load().dclr_oracle_num_threads())
+
+
+def set_threads(n: int) -> None:
+    _load().dclr_oracle_set_threads(int(n))
 
 
 def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
