@@ -82,6 +82,21 @@ __device__ __forceinline__ float dclr_wave_max_nonneg(float v) {
     return __uint_as_float(dclr_wave_max_u32(__float_as_uint(v)));
 }
 
+// Read-only, wave-uniform parameter tables (MLP weights): viewing them through the constant address
+// space lets the compiler keep s_load (scalar operands) even when workgroup fences sit between
+// loads -- a fence otherwise counts as a clobber and demotes them to hoisted vector loads.
+typedef const float __attribute__((address_space(4))) *dclr_const_f32p;
+__device__ __forceinline__ dclr_const_f32p dclr_as_const(const float *p) { return (dclr_const_f32p)p; }
+
+// Arguments of a non-inlined device function arrive in VGPRs; these re-establish wave uniformity.
+__device__ __forceinline__ int dclr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float *dclr_uniform(const float *p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const float *)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int dclr_lane() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ uint32_t dclr_lanemask_lt_popc(uint64_t mask) {

@@ -7,13 +7,16 @@
 // materialises (clouds, {4,16,16,32}, npoint, nsample) tensors (~856 MB per KITTI pair);
 // here nothing but the 64 pooled features per centroid ever leaves the CU.
 //
-// One wave per centroid:
-//   phase 1  sweep the cloud 64 points per step (coalesced), ballot the in-radius lanes of every
-//            scale and append their indices, in ascending point order, to per-wave LDS lists capped
-//            at nsample -- exactly the index set the published ball query keeps;
-//   phase 2  per scale, 64 neighbours at a time (lane = neighbour): build [p - c, features], run
-//            the three 1x1-conv layers in registers with the weights as scalar operands, keep a
-//            running per-lane maximum, finally DPP-reduce the 32 channels across the wave.
+// Workgroup = 4 waves x 4 centroids of one cloud.
+//   sweep   the cloud streams once per workgroup through double-buffered LDS tiles (512 points,
+//           padded to float4); every wave tests each 64-point slice against its 4 centroids (scalar
+//           coordinates) and both radii. In-radius lanes are ballot-compacted, in ascending point
+//           order and capped at nsample per (centroid, scale) -- exactly the index set the published
+//           ball query keeps -- into one small per-wave, per-scale ring of (centroid, point) entries.
+//   drain   whenever a ring holds 64 entries (and once at the end for the remainder) the wave calls
+//           sa_drain: the shared MLP with lane = entry and all weights as scalar operands, a
+//           64 x 32 transpose through LDS and a segmented maximum per centroid slot, folded by the
+//           caller into per-(scale, centroid) running maxima held by lane = (row parity, channel).
 // Slots that would only repeat the first hit are skipped: max() over a multiset equals max() over
 // its support, so the result is identical. A centroid with no hit reproduces the published
 // behaviour (zero-filled index row => every slot is point 0).
@@ -22,34 +25,37 @@
 namespace {
 
 constexpr int SA_WAVES = 4;
+constexpr int SA_CPW = 4;                       // centroids per wave
+constexpr int SA_TILE = 512;                    // points per LDS tile
+constexpr int SA_RING = 512;                    // ring capacity (>= 63 + SA_CPW * 64), power of two
 constexpr int SA_MAX_SCALES = 2;
 constexpr int SA_H1 = 16, SA_H2 = 16, SA_OUT = 32;
+constexpr int SA_OSTRIDE = SA_OUT + 1;          // output row: 32 channels + centroid tag, odd stride
 
 struct SaParams {
     int n, npoint, n_scales;
     float radius2[SA_MAX_SCALES];
+    float radius2_max;
     int nsample[SA_MAX_SCALES];
-    int list_off[SA_MAX_SCALES];       // offset of each scale's list inside a wave's LDS region
-    int list_total;                    // ints per wave
     const float *mlp[SA_MAX_SCALES];
 };
 
 template <int C>
-__device__ __forceinline__ void sa_load_point(const float *__restrict__ cloud, int k, float (&v)[C]) {
+__device__ __forceinline__ float4 sa_load_point(const float *__restrict__ cloud, int k) {
     if constexpr (C == 4) {
-        const float4 q = *reinterpret_cast<const float4 *>(cloud + (size_t)k * 4);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        return *reinterpret_cast<const float4 *>(cloud + (size_t)k * 4);
     } else {
-#pragma unroll
-        for (int i = 0; i < C; ++i) v[i] = cloud[(size_t)k * C + i];
+        const float *p = cloud + (size_t)k * 3;
+        return make_float4(p[0], p[1], p[2], 0.f);
     }
 }
 
 // 3-layer shared MLP on one neighbour; weights are wave-uniform (scalar loads).
 template <int C>
-__device__ __forceinline__ void sa_mlp(const float *__restrict__ w, const float (&in)[C], float (&out)[SA_OUT]) {
-    const float *w1 = w, *b1 = w1 + SA_H1 * C, *w2 = b1 + SA_H1, *b2 = w2 + SA_H2 * SA_H1;
-    const float *w3 = b2 + SA_H2, *b3 = w3 + SA_OUT * SA_H2;
+__device__ __forceinline__ void sa_mlp(const float *w_global, const float (&in)[4], float (&out)[SA_OUT]) {
+    dclr_const_f32p w1 = dclr_as_const(w_global);
+    dclr_const_f32p b1 = w1 + SA_H1 * C, w2 = b1 + SA_H1, b2 = w2 + SA_H2 * SA_H1;
+    dclr_const_f32p w3 = b2 + SA_H2, b3 = w3 + SA_OUT * SA_H2;
     float h1[SA_H1], h2[SA_H2];
 #pragma unroll
     for (int o = 0; o < SA_H1; ++o) {
@@ -74,88 +80,186 @@ __device__ __forceinline__ void sa_mlp(const float *__restrict__ w, const float 
     }
 }
 
+// Workgroup-shared state. Namespace scope so that the (deliberately not inlined) drain routine can
+// address it; both template instances of the kernel use the same layout.
+__shared__ float4 sa_tile[2][SA_TILE];
+__shared__ uint32_t sa_ring[SA_WAVES][SA_MAX_SCALES][SA_RING];
+__shared__ float sa_obuf[SA_WAVES][64 * SA_OSTRIDE];
+__shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
+
+struct SaMax4 {
+    float v[SA_CPW];
+};
+
+// One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`, lane = entry. Returns,
+// for lane = (row parity, channel), the maxima of this pass per centroid slot; the caller folds them
+// into its running maxima. Kept out of line on purpose: inlined into the sweep loop its ~100 scalar
+// weight registers push the loop-carried scalars (centroids, counters) into spill lanes.
+template <int C>
+__device__ __noinline__ SaMax4 sa_drain(const float *cloud, const float *mlp, int wave, int s, int head, int take) {
+    cloud = dclr_uniform(cloud); mlp = dclr_uniform(mlp);
+    wave = dclr_uniform(wave); s = dclr_uniform(s); head = dclr_uniform(head); take = dclr_uniform(take);
+    const int lane = dclr_lane();
+    const bool valid = lane < take;
+    const uint32_t e = valid ? sa_ring[wave][s][(head + lane) & (SA_RING - 1)] : 0u;
+    const int c = (int)(e >> 16), k = (int)(e & 0xFFFFu);
+    const float4 p = sa_load_point<C>(cloud, k);
+    float in[4] = {p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w};
+    float h[SA_OUT];
+    sa_mlp<C>(mlp, in, h);
+    float *orow = &sa_obuf[wave][lane * SA_OSTRIDE];
+#pragma unroll
+    for (int o = 0; o < SA_OUT; ++o) orow[o] = h[o];
+    orow[SA_OUT] = __int_as_float(c);
+    // rows of one wave only: the wave's own LDS writes are ordered before its reads
+    SaMax4 out;
+#pragma unroll
+    for (int cc = 0; cc < SA_CPW; ++cc) out.v[cc] = 0.f;
+    const int ch = lane & 31;
+    for (int r = lane >> 5; r < take; r += 2) {
+        const float v = sa_obuf[wave][r * SA_OSTRIDE + ch];
+        const int rc = __float_as_int(sa_obuf[wave][r * SA_OSTRIDE + SA_OUT]);
+#pragma unroll
+        for (int cc = 0; cc < SA_CPW; ++cc) out.v[cc] = rc == cc ? fmaxf(out.v[cc], v) : out.v[cc];
+    }
+    return out;
+}
+
 template <int C>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                                                                const float *__restrict__ clouds,
                                                                const int32_t *__restrict__ fps_idx,
                                                                float *__restrict__ out_rows,
                                                                int32_t *__restrict__ counts) {
-    extern __shared__ int32_t lists[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = blockIdx.x * SA_WAVES + wave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t bi = blockIdx.y;
-    if (j >= prm.npoint) return;                                    // wave-uniform
+    const int j0 = (blockIdx.x * SA_WAVES + wave) * SA_CPW;          // this wave's first centroid
     const float *cloud = clouds + bi * (size_t)prm.n * C;
-    int32_t *mylist = lists + wave * prm.list_total;
 
-    const int ck = fps_idx[bi * prm.npoint + j];
-    const float cx = cloud[(size_t)ck * C + 0], cy = cloud[(size_t)ck * C + 1], cz = cloud[(size_t)ck * C + 2];
-
-    // ---- phase 1: ball query for all scales in one sweep ----------------------------------------
-    int cnt[SA_MAX_SCALES] = {0, 0};
-    bool open = true;
-    for (int base = 0; base < prm.n && open; base += 64) {
-        const int k = base + lane;
-        float d2 = 3.0e38f;
-        if (k < prm.n) {
-            float p[C];
-            sa_load_point<C>(cloud, k, p);
-            d2 = dclr_sqdist(cx, cy, cz, p[0], p[1], p[2]);
+    // centroids of this wave; a slot past the end of the cloud's centroid list starts "full" so the
+    // sweep never records a hit for it
+    float ccx[SA_CPW], ccy[SA_CPW], ccz[SA_CPW];
+    int cnt[SA_CPW][SA_MAX_SCALES];
+    const int n_live = prm.npoint - j0 < SA_CPW ? prm.npoint - j0 : SA_CPW;
+#pragma unroll
+    for (int c = 0; c < SA_CPW; ++c) {
+        const bool live = c < n_live;
+        const int jc = live ? j0 + c : prm.npoint - 1;
+        const int ck = __builtin_amdgcn_readfirstlane(fps_idx[bi * prm.npoint + jc]);
+        const float4 q = sa_load_point<C>(cloud, ck);
+        ccx[c] = q.x; ccy[c] = q.y; ccz[c] = q.z;                    // wave-uniform values kept in VGPRs
+        if (lane == 0) {
+            sa_cxyz[wave][c][0] = q.x; sa_cxyz[wave][c][1] = q.y; sa_cxyz[wave][c][2] = q.z; sa_cxyz[wave][c][3] = 0.f;
         }
-        open = false;
+        cnt[c][0] = live ? 0 : prm.nsample[0];
+        cnt[c][1] = live ? 0 : prm.nsample[1];
+    }
+
+    int qhead[SA_MAX_SCALES] = {0, 0}, qn[SA_MAX_SCALES] = {0, 0};
+    float mx[SA_MAX_SCALES][SA_CPW];                                    // lane = (row parity, channel)
+#pragma unroll
+    for (int s = 0; s < SA_MAX_SCALES; ++s)
+#pragma unroll
+        for (int c = 0; c < SA_CPW; ++c) mx[s][c] = 0.f;                // post-ReLU values are >= 0
+
+    const int n_tiles = (prm.n + SA_TILE - 1) / SA_TILE;
+    constexpr int PER_THREAD = SA_TILE / (SA_WAVES * 64);               // points staged per thread
+    float4 stage[PER_THREAD];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int k = t * SA_TILE + u * (SA_WAVES * 64) + tid;
+            stage[u] = k < prm.n ? sa_load_point<C>(cloud, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) sa_tile[buf][u * (SA_WAVES * 64) + tid] = stage[u];
+    };
+    fetch(0);
+    stash(0);
+
+    auto drain_all = [&](bool final_pass) {
 #pragma unroll
         for (int s = 0; s < SA_MAX_SCALES; ++s) {
             if (s >= prm.n_scales) break;
-            if (cnt[s] < prm.nsample[s]) {
-                const bool hit = d2 < prm.radius2[s];
-                const uint64_t mask = __ballot(hit);
-                const int pos = cnt[s] + (int)dclr_lanemask_lt_popc(mask);
-                if (hit && pos < prm.nsample[s]) mylist[prm.list_off[s] + pos] = k;
-                cnt[s] += __builtin_popcountll(mask);
-                if (cnt[s] < prm.nsample[s]) open = true;
+            while (qn[s] >= 64 || (final_pass && qn[s] > 0)) {
+                const int take = qn[s] < 64 ? qn[s] : 64;
+                const SaMax4 r = sa_drain<C>(cloud, prm.mlp[s], wave, s, qhead[s], take);
+#pragma unroll
+                for (int c = 0; c < SA_CPW; ++c) mx[s][c] = fmaxf(mx[s][c], r.v[c]);
+                qhead[s] += take;
+                qn[s] -= take;
             }
         }
+    };
+
+    for (int t = 0; t < n_tiles; ++t) {
+        __syncthreads();                                   // tile t is in sa_tile[t & 1]
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) fetch(t + 1);
+        for (int it = 0; it < SA_TILE / 64; ++it) {
+            const int k = t * SA_TILE + it * 64 + lane;
+            const float4 p = sa_tile[buf][it * 64 + lane];
+            const bool inb = k < prm.n;
+            float d2c[SA_CPW];
+#pragma unroll
+            for (int c = 0; c < SA_CPW; ++c) d2c[c] = dclr_sqdist(ccx[c], ccy[c], ccz[c], p.x, p.y, p.z);
+            // common case: no lane is inside the largest ball of any of the wave's centroids
+            const float dmin = fminf(fminf(d2c[0], d2c[1]), fminf(d2c[2], d2c[3]));
+            if (__ballot(inb && dmin < prm.radius2_max) == 0) continue;
+#pragma unroll
+            for (int c = 0; c < SA_CPW; ++c) {
+                const float d2 = d2c[c];
+#pragma unroll
+                for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                    if (s >= prm.n_scales) break;
+                    const bool hit = inb && d2 < prm.radius2[s];
+                    const uint64_t mask = __ballot(hit);
+                    if (__builtin_expect(mask != 0 && cnt[c][s] < prm.nsample[s], 0)) {   // wave-uniform, rare
+                        const int room = prm.nsample[s] - cnt[c][s];
+                        const int pre = (int)dclr_lanemask_lt_popc(mask);
+                        int nt = __builtin_popcountll(mask);
+                        nt = nt < room ? nt : room;
+                        if (hit && pre < room)
+                            sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = ((uint32_t)c << 16) | (uint32_t)k;
+                        qn[s] += nt;
+                        cnt[c][s] += nt;
+                    }
+                }
+            }
+            if (__builtin_expect(qn[0] >= 64 || qn[1] >= 64, 0)) drain_all(false);
+        }
+        if (t + 1 < n_tiles) stash(buf ^ 1);
     }
 
-    float *orow = out_rows + (bi * prm.npoint + j) * DCLR_F_STRIDE;
+    // published behaviour for a centroid without any hit: its (zero-filled) index row means point 0
+#pragma unroll
+    for (int c = 0; c < SA_CPW; ++c)
+#pragma unroll
+        for (int s = 0; s < SA_MAX_SCALES; ++s) {
+            if (s >= prm.n_scales) break;
+            if (c < n_live && cnt[c][s] == 0) {
+                if (lane == 0) sa_ring[wave][s][(qhead[s] + qn[s]) & (SA_RING - 1)] = (uint32_t)c << 16;
+                qn[s] += 1;
+            }
+        }
+    drain_all(true);
 
-    // ---- phase 2: shared MLP + max over each neighbourhood ---------------------------------------
 #pragma unroll
-    for (int s = 0; s < SA_MAX_SCALES; ++s) {
-        if (s >= prm.n_scales) break;
-        int n_nb = cnt[s] < prm.nsample[s] ? cnt[s] : prm.nsample[s];
-        if (counts) {
-            if (lane == 0) counts[(bi * prm.npoint + j) * prm.n_scales + s] = n_nb;
+    for (int c = 0; c < SA_CPW; ++c) {
+        if (c >= n_live) break;
+        float *orow = out_rows + (bi * prm.npoint + j0 + c) * DCLR_F_STRIDE;
+        float v = 0.f;                                                  // columns of an absent scale stay zero
+#pragma unroll
+        for (int s = 0; s < SA_MAX_SCALES; ++s) {
+            const float m = fmaxf(mx[s][c], __shfl_xor(mx[s][c], 32));   // rows were split over the lane halves
+            if (s < prm.n_scales && (lane >> 5) == s) v = m;
         }
-        const bool empty = n_nb == 0;       // published behaviour: zero index row => point 0 everywhere
-        if (empty) n_nb = 1;
-        float best[SA_OUT];
-#pragma unroll
-        for (int o = 0; o < SA_OUT; ++o) best[o] = 0.f;             // post-ReLU values are >= 0
-        for (int base = 0; base < n_nb; base += 64) {
-            const int e = base + lane;
-            const bool valid = e < n_nb;
-            int nb = 0;
-            if (valid && !empty) nb = mylist[prm.list_off[s] + e];
-            float p[C], h[SA_OUT];
-            sa_load_point<C>(cloud, nb, p);
-            p[0] -= cx; p[1] -= cy; p[2] -= cz;
-            sa_mlp<C>(prm.mlp[s], p, h);
-#pragma unroll
-            for (int o = 0; o < SA_OUT; ++o) best[o] = valid ? fmaxf(best[o], h[o]) : best[o];
-        }
-        float mine = 0.f;
-#pragma unroll
-        for (int o = 0; o < SA_OUT; ++o) {
-            const float r = dclr_wave_max_nonneg(best[o]);
-            mine = lane == o ? r : mine;
-        }
-        if (lane < SA_OUT) orow[s * SA_OUT + lane] = mine;
-    }
-    // columns not covered by a scale stay zero; xyz + pad
-    if (lane >= prm.n_scales * SA_OUT && lane < 64) orow[lane] = 0.f;
-    if (lane == 0) {
-        orow[64] = cx; orow[65] = cy; orow[66] = cz; orow[67] = 0.f;
+        orow[lane] = v;                                                 // lane = s * 32 + channel
+        if (lane < 4) orow[64 + lane] = lane == 0 ? ccx[c] : (lane == 1 ? ccy[c] : (lane == 2 ? ccz[c] : 0.f));
+        if (counts && lane < prm.n_scales)
+            counts[(bi * prm.npoint + j0 + c) * prm.n_scales + lane] = lane == 0 ? cnt[c][0] : cnt[c][1];
     }
 }
 
@@ -193,26 +297,23 @@ extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *c
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
+    if (n > 65536) return DCLR_E_UNSUPPORTED;                 // ring entries hold 16-bit point indices
     SaParams prm{};
     prm.n = n; prm.npoint = npoint; prm.n_scales = n_scales;
-    int total = 0;
     for (int s = 0; s < n_scales; ++s) {
         DCLR_REQUIRE(nsamples_host[s] > 0 && mlp_host_ptrs[s]);
         prm.radius2[s] = radii_host[s] * radii_host[s];
+        prm.radius2_max = s == 0 || prm.radius2[s] > prm.radius2_max ? prm.radius2[s] : prm.radius2_max;
         prm.nsample[s] = nsamples_host[s];
-        prm.list_off[s] = total;
-        total += nsamples_host[s];
         prm.mlp[s] = mlp_host_ptrs[s];
     }
-    prm.list_total = total;
-    const size_t lds = (size_t)SA_WAVES * total * sizeof(int32_t);
-    if (lds > 64 * 1024) return DCLR_E_UNSUPPORTED;
-    dim3 grid((npoint + SA_WAVES - 1) / SA_WAVES, b);
+    constexpr int per_wg = SA_WAVES * SA_CPW;
+    dim3 grid((npoint + per_wg - 1) / per_wg, b);
     if (c == 4)
-        hipLaunchKernelGGL((sa_msg_kernel<4>), grid, dim3(SA_WAVES * 64), lds, (hipStream_t)stream, prm, clouds,
+        hipLaunchKernelGGL((sa_msg_kernel<4>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,
                            fps_idx, out_rows, counts);
     else
-        hipLaunchKernelGGL((sa_msg_kernel<3>), grid, dim3(SA_WAVES * 64), lds, (hipStream_t)stream, prm, clouds,
+        hipLaunchKernelGGL((sa_msg_kernel<3>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,
                            fps_idx, out_rows, counts);
     return dclr_launch_status();
 }

@@ -116,6 +116,44 @@ def test_fused_stages_against_oracle(kind, n, pairs):
     assert pose_delta(_mats(y_full), mats_o) < 1e-4
 
 
+@pytest.mark.parametrize('c,n,npoint,radii,nsamples', [
+    (3, 2048, 100, (0.3, 0.6), (64, 128)),      # dense: every neighbourhood overflows its cap, drains mid-sweep
+    (4, 1500, 37, (0.25, 5.0), (16, 700)),      # one scale sparse, one that swallows half the cloud; ragged tail
+    (4, 777, 64, (0.05,), (8,)),                # single scale
+])
+def test_fused_set_abstraction_dense_neighbourhoods(c, n, npoint, radii, nsamples):
+    from deepclr_amd.pointnet2 import PointnetSAModuleMSG
+    rng = np.random.default_rng(n)
+    pts = rng.normal(size=(2, n, 3))
+    pts /= np.linalg.norm(pts, axis=2, keepdims=True)
+    pts *= rng.uniform(0.2, 1.0, size=(2, n, 1))
+    x_np = np.concatenate((pts, rng.uniform(size=(2, n, c - 3))), axis=2).astype(np.float32)
+    torch.manual_seed(5)
+    sam = PointnetSAModuleMSG(npoint=npoint, radii=list(radii), nsamples=list(nsamples),
+                              mlps=[[c - 3, 16, 16, 32] for _ in radii], bn=False, use_xyz=True)
+    for prm in sam.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.uniform_(prm, -0.1, 0.1)
+    x = torch.from_numpy(x_np)
+    xyz = x[:, :, :3].contiguous()
+    feats = x[:, :, 3:].transpose(1, 2).contiguous() if c > 3 else None
+    weights = [[(u.conv.weight.detach(), u.conv.bias.detach()) for u in stack] for stack in sam.mlps]
+    from oracle.model import sa_msg_forward
+    new_xyz_o, feat_o = sa_msg_forward(xyz, feats, npoint, list(radii), list(nsamples), weights)
+    sam = sam.to(DEV)
+    with torch.no_grad():
+        new_xyz, feat = sam(xyz.to(DEV), None if feats is None else feats.to(DEV))
+    assert torch.equal(new_xyz.cpu(), new_xyz_o)
+    _close(feat, feat_o)
+    fps = ops.fps_clouds(x.to(DEV), npoint)
+    _, counts = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True)
+    for s, (r, ns) in enumerate(zip(radii, nsamples)):
+        bq = oracle.ball_query(r, ns, xyz, new_xyz_o)
+        hits = 1 + (bq[:, :, 1:] != bq[:, :, :1]).sum(-1)
+        assert torch.equal(counts[:, :, s].cpu(), hits.to(torch.int32))
+        assert (hits == ns).any() or r < 0.1
+
+
 def test_radius_mask_is_exercised():
     """ModelNet arch: flow-embedding radius 0.2 with k = 30 of 512 points masks many neighbours."""
     cfg = synthetic.model_cfg('modelnet')
