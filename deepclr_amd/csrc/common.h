@@ -27,9 +27,12 @@ __device__ __forceinline__ float dclr_sqdist(float ax, float ay, float az, float
 }
 
 // ---- DPP wave reductions over u32 (result broadcast through an SGPR).
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ uint32_t dclr_dpp(uint32_t old, uint32_t src) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+// `old` is the operation's identity, so lanes a DPP control leaves unwritten contribute nothing and
+// hipcc folds each step into one v_max_u32_dpp / v_min_u32_dpp (passing `old = v` costs 4 instructions
+// per step instead of 1 on the serial path of the sampling loop).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dclr_dpp(uint32_t identity, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)src, CTRL, ROW_MASK, 0xf, false);
 }
 
 #define DCLR_DPP_ROW_SHR(n) (0x110 + (n))
@@ -39,42 +42,43 @@ __device__ __forceinline__ uint32_t dclr_dpp(uint32_t old, uint32_t src) {
 __device__ __forceinline__ uint32_t dclr_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t dclr_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-// Inclusive "scan to the right" with an idempotent op: lane 63 ends up with the wave result.
+// Inclusive "scan to the right" with an idempotent op: lane 15 of each row, then lane 63, end up
+// with the row / wave result.
+__device__ __forceinline__ uint32_t dclr_row16_max_lanes(uint32_t v) {
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf>(0u, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf>(0u, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf>(0u, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf>(0u, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t dclr_row16_min_lanes(uint32_t v) {
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf>(0xFFFFFFFFu, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf>(0xFFFFFFFFu, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf>(0xFFFFFFFFu, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf>(0xFFFFFFFFu, v));
+    return v;
+}
+
 __device__ __forceinline__ uint32_t dclr_wave_max_u32(uint32_t v) {
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc, 0xf>(v, v));
+    v = dclr_row16_max_lanes(v);
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa>(0u, v));
+    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc>(0u, v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ uint32_t dclr_wave_min_u32(uint32_t v) {
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc, 0xf>(v, v));
+    v = dclr_row16_min_lanes(v);
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST15, 0xa>(0xFFFFFFFFu, v));
+    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_BCAST31, 0xc>(0xFFFFFFFFu, v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // Same over the first 16 lanes only (one DPP row): lane 15 holds the result.
 __device__ __forceinline__ uint32_t dclr_row16_max_u32(uint32_t v) {
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
-    v = dclr_umax(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+    return (uint32_t)__builtin_amdgcn_readlane((int)dclr_row16_max_lanes(v), 15);
 }
-
 __device__ __forceinline__ uint32_t dclr_row16_min_u32(uint32_t v) {
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf, 0xf>(v, v));
-    v = dclr_umin(v, dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf, 0xf>(v, v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+    return (uint32_t)__builtin_amdgcn_readlane((int)dclr_row16_min_lanes(v), 15);
 }
 
 // Wave max over f32 for values >= 0 (bit pattern order == value order).

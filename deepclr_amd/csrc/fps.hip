@@ -16,7 +16,16 @@
 //     smallest bit-reversed (k mod T), then the smallest k / T, wins -- independent of how points
 //     are laid out over threads here;
 //   * sampled indices are collected in LDS and written once at the end (no global store, hence no
-//     vmcnt wait, inside the serial loop).
+//     vmcnt wait, inside the serial loop);
+//   * (clouds of 1025..16384 points) the kernel first sorts the cloud by a coarse Morton key in LDS,
+//     so that each wave owns a spatially compact 1/16 of the cloud, and from then on a region whose
+//     bounding box is farther from the new sample than its largest running minimum skips the
+//     round entirely: with the same rounded operation sequence, distance-to-box <= distance-to-point
+//     (rounding is monotone), so no running minimum of that wave could change and its cached
+//     candidate stays exact. The test runs per group of 4 register slots (64 compact regions of 256
+//     points per cloud); typically a handful of the 64 groups do work in a round.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -263,6 +272,381 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int pstride, in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Kernel A': as kernel A, plus spatial sorting and per-wave pruning. 1024 threads, T == 1024,
+// 1024 < n <= 1024 * P, P a power of two.
+// ------------------------------------------------------------------------------------------------
+// Tie key for T == 1024 in 16 bits (n <= 65536): same order as fps_tiekey(k, 1023, 10), invertible.
+__device__ __forceinline__ uint32_t fps_tk1024(uint32_t k) { return ((__brev(k & 1023u) >> 22) << 6) | (k >> 10); }
+__device__ __forceinline__ uint32_t fps_tk1024_inv(uint32_t tk) { return (__brev(tk >> 6) >> 22) | ((tk & 63u) << 10); }
+
+__device__ __forceinline__ float fps_shfl_min(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float fps_shfl_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Rounded lower bound of dclr_sqdist(p, c) over all p inside the box [lo, hi] (same operation
+// sequence as dclr_sqdist; see the header comment for why it is a bound on the ROUNDED distance).
+__device__ __forceinline__ float fps_box_lower_bound(float lx, float ly, float lz, float hx, float hy, float hz,
+                                                     float cx, float cy, float cz) {
+    const float dx = fmaxf(fmaxf(lx - cx, cx - hx), 0.f);
+    const float dy = fmaxf(fmaxf(ly - cy, cy - hy), 0.f);
+    const float dz = fmaxf(fmaxf(lz - cz, cz - hz), 0.f);
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+#ifdef FPS_DEBUG
+__device__ unsigned long long fps_dbg[16];     // [0] active (wave, round) count, [1..] cycle sums (wave 0)
+#define FPS_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#endif
+
+struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
+    int32_t k;
+    float x, y, z;
+};
+
+// WGS threads, P points per thread (WGS * P = padded cloud size, a power of two), G groups per wave.
+template <int WGS, int P, int G>
+__global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int m,
+                                                         const float *__restrict__ pts,
+                                                         float *__restrict__ temp,
+                                                         int32_t *__restrict__ idx) {
+    constexpr int NW = WGS / 64, NP = WGS * P, BINS = 4096, S = P / G;
+    static_assert(P % G == 0 && G <= 16 && NW <= 16 && BINS % WGS == 0, "layout");
+    typedef typename VecOf<P>::type vec;
+    __shared__ unsigned long long cell[3];                 // per-round 64-bit arg-max cells, rotated
+    __shared__ FpsCand cand[2][16];                        // per-wave candidate payload, by round parity
+    __shared__ float red[6][16];
+    __shared__ uint32_t wsum[16];
+    extern __shared__ uint32_t dyn_lds[];                  // BINS counters, NP sorted keys, max(NP, m) scratch/picked
+    uint32_t *hist = dyn_lds;
+    uint32_t *sbuf = dyn_lds + BINS;
+    int32_t *picked = reinterpret_cast<int32_t *>(dyn_lds + BINS + NP);   // shares storage with `cellof`
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    pts += (size_t)blockIdx.x * n * pstride;
+    idx += (size_t)blockIdx.x * m;
+    if (temp) temp += (size_t)blockIdx.x * n;
+
+    // ---- 1. bounding box of the cloud --------------------------------------------------------------
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = t + WGS * j;
+        if (k < n) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = pts[(size_t)k * pstride + a];
+                lo[a] = fminf(lo[a], v);
+                hi[a] = fmaxf(hi[a], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = fps_shfl_min(lo[a]), h = fps_shfl_max(hi[a]);
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+#pragma unroll
+    for (int u = 0; u < BINS / WGS; ++u) hist[t + WGS * u] = 0u;
+    if (t < 3) cell[t] = 0ull;
+    if (t < 32) cand[t >> 4][t & 15] = FpsCand{0, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        lo[a] = l;
+        ext = fmaxf(ext, h - l);
+    }
+    // ---- 2. counting sort by a 12-bit Morton cell (4 bits per axis, one common cell size). The sort
+    //         only decides which wave owns which point; any order yields the same samples. -----------
+    const float scale = ext > 0.f ? 15.999f / ext : 0.f;
+    uint32_t *cellof = sbuf + NP;                          // scratch list of cell ids, dead before `picked` is used
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = t + WGS * j;
+        uint32_t mc = 0u;
+        if (k < n) {
+            uint32_t q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int c = (int)((pts[(size_t)k * pstride + a] - lo[a]) * scale);
+                q[a] = (uint32_t)(c < 0 ? 0 : (c > 15 ? 15 : c));
+            }
+#pragma unroll
+            for (int bit = 0; bit < 4; ++bit)
+                mc |= (((q[0] >> bit) & 1u) << (3 * bit)) | (((q[1] >> bit) & 1u) << (3 * bit + 1)) |
+                      (((q[2] >> bit) & 1u) << (3 * bit + 2));
+            atomicAdd(&hist[mc], 1u);
+            cellof[k] = mc;
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the counters: BPT per thread, wave scan, NW wave totals
+        constexpr int BPT = BINS / WGS;
+        uint32_t c[BPT], mine = 0;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { c[u] = hist[BPT * t + u]; mine += c[u]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { hist[BPT * t + u] = run; run += c[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = t + WGS * j;
+        if (k < n) sbuf[atomicAdd(&hist[cellof[k]], 1u)] = (uint32_t)k;
+    }
+    __syncthreads();
+    // ---- 3. this thread's points: wave w owns sorted positions [w*64*P, (w+1)*64*P); its P register
+    //         slots form G groups of S consecutive slots, i.e. G spatially compact runs of 64*S points.
+    // Inside each group of a thread the tie keys ascend, so a strict ">" scan over the group keeps the
+    // right point on equal distances; groups and lanes are merged with an explicit key comparison.
+    // The sorted keys go back to LDS (same positions, now in slot order): the hot loop never needs
+    // them in registers, only the winner's key is fetched once per round.
+    uint32_t *skey = sbuf + wave * 64 * P + lane;          // this thread's key of slot jj: skey[jj * 64]
+    vec px, py, pz, td;
+    float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};   // lane g: box of group g
+    float gmaxv = 0.f;                                     // lane g: upper bound of group g's largest running minimum;
+                                                           // 0 for an empty group (its box bound is +inf: never active)
+    float gbest[G];                                        // per lane: largest running minimum inside the group
+    int gjj[G];                                            // ... and the slot holding it (first one in key order)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        uint32_t tkg[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int pos = wave * 64 * P + (g * S + i) * 64 + lane;
+            tkg[i] = pos < n ? fps_tk1024(sbuf[pos]) : 0xFFFFu;
+        }
+#pragma unroll
+        for (int k2 = 2; k2 <= S; k2 <<= 1)
+#pragma unroll
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const int l = i ^ j2;
+                    if (l > i) {
+                        const uint32_t a = tkg[i], b = tkg[l];
+                        const uint32_t mn = a < b ? a : b, mxv = a < b ? b : a;
+                        const bool asc = (i & k2) == 0;
+                        tkg[i] = asc ? mn : mxv;
+                        tkg[l] = asc ? mxv : mn;
+                    }
+                }
+        float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int jj = g * S + i;
+            skey[jj * 64] = tkg[i];                        // own positions only: no cross-thread hazard
+            float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;   // -2: padding can never beat best = -1
+            if (tkg[i] != 0xFFFFu) {
+                const uint32_t k = fps_tk1024_inv(tkg[i]);
+                x = pts[(size_t)k * pstride + 0];
+                y = pts[(size_t)k * pstride + 1];
+                z = pts[(size_t)k * pstride + 2];
+                d = temp ? temp[k] : 1e10f;
+                blo[0] = fminf(blo[0], x); blo[1] = fminf(blo[1], y); blo[2] = fminf(blo[2], z);
+                bhi[0] = fmaxf(bhi[0], x); bhi[1] = fmaxf(bhi[1], y); bhi[2] = fmaxf(bhi[2], z);
+                any = true;
+            }
+            vec_set<P>(px, jj, x); vec_set<P>(py, jj, y); vec_set<P>(pz, jj, z); vec_set<P>(td, jj, d);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = fps_shfl_min(blo[a]), h = fps_shfl_max(bhi[a]);
+            if (lane == g) { glo[a] = l; ghi[a] = h; }
+        }
+        gbest[g] = any ? 0.f : -1.0f;
+        gjj[g] = g * S;
+        if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
+    }
+    __syncthreads();                                       // `cellof` is dead: `picked` (same storage) may be written
+
+    float cx = pts[0], cy = pts[1], cz = pts[2];
+    if (t == 0) picked[0] = 0;
+
+    unsigned long long c_packed = (unsigned long long)wave;      // best 0, worst key: never wins against a real point
+    int32_t c_k = 0;
+    float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+    int fresh = 0;                                                // rounds for which cand[parity][wave] is still stale
+
+#ifdef FPS_DEBUG
+    unsigned long long t_setup;
+    FPS_STAMP(t_setup);
+    unsigned long long acc_upd = 0, acc_bar = 0, acc_comb = 0, n_act = 0;
+    unsigned long long dbg_box = 0, dbg_upd = 0, dbg_sel = 0, dbg_pub = 0, dbg_idle = 0, dbg_nact = 0;
+#endif
+    int c3 = 1;                                                   // r % 3
+    for (int r = 1; r < m; ++r) {
+#ifdef FPS_DEBUG
+        unsigned long long s0, s1, s2, s3;
+        FPS_STAMP(s0);
+#endif
+        // lanes 0..G-1 test the G group boxes at once: group g needs work iff the rounded lower bound
+        // of its distance to the new sample is below its largest running minimum
+        const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], cx, cy, cz);
+        const uint32_t act = (uint32_t)__ballot(lbv < gmaxv);
+#ifdef FPS_DEBUG
+        unsigned long long a0 = 0, a1 = 0, a2 = 0;
+        FPS_STAMP(a0);
+#endif
+        if (act != 0) {                                           // wave-uniform
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (act & (1u << g)) {
+#ifdef FPS_DEBUG
+                    n_act += 1;
+#endif
+                    float best = -1.0f;
+                    int bjj = g * S;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const int jj = g * S + i;
+                        const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), cx, cy, cz);
+                        float d2;                           // plain v_min_f32: no canonicalising v_max in front of it
+                        asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                        vec_set<P>(td, jj, d2);
+                        const bool gt = d2 > best;
+                        bjj = gt ? jj : bjj;
+                        best = gt ? d2 : best;
+                    }
+                    gbest[g] = best; gjj[g] = bjj;
+                }
+            }
+            // Running minima only decrease, so a stale group maximum stays a valid (conservative) bound
+            // for the test above; the bounds are tightened every 8th round instead of on every update.
+            if ((r & 7) == 1) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float gm = __uint_as_float(dclr_wave_max_u32(gbest[g] < 0.f ? 0u : __float_as_uint(gbest[g])));
+                    gmaxv = lane == g ? gm : gmaxv;
+                }
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(a1);
+#endif
+            float lbest = gbest[0];
+#pragma unroll
+            for (int g = 1; g < G; ++g) lbest = fmaxf(lbest, gbest[g]);
+            const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
+            const float wmaxf = __uint_as_float(wmax);
+            // how many (lane, group) candidates carry the wave maximum? exactly one unless distances tie
+            int hits = 0, hjj = 0;
+#pragma unroll
+            for (int g = G - 1; g >= 0; --g) {
+                const bool eq = gbest[g] == wmaxf;
+                hits += eq ? 1 : 0;
+                hjj = eq ? gjj[g] : hjj;
+            }
+            const uint64_t lanes_hit = __ballot(hits > 0);
+            int wl, wjj;
+            uint32_t wkey;
+            if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
+                wl = __builtin_ctzll(lanes_hit);
+                wjj = __builtin_amdgcn_readlane(hjj, wl);
+                wkey = sbuf[wave * 64 * P + wjj * 64 + wl];                               // uniform address
+            } else {
+                // exact tie (duplicate points, lattices, exhausted cloud): smallest tie key among all
+                // candidates. A group's cached slot already is its lowest-key maximum (ascending keys,
+                // strict ">"), so only groups and lanes have to be merged here.
+                uint32_t key = 0xFFFFFFFFu;
+                int kjj = 0;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    uint32_t kg = 0xFFFFu;
+                    if (gbest[g] == wmaxf) kg = skey[gjj[g] * 64];
+                    const bool take = gbest[g] == wmaxf && kg < key;
+                    key = take ? kg : key;
+                    kjj = take ? gjj[g] : kjj;
+                }
+                wkey = dclr_wave_min_u32(key);
+                wl = __builtin_ctzll(__ballot(key == wkey));
+                wjj = __builtin_amdgcn_readlane(kjj, wl);
+            }
+            c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - wkey) << 16) |
+                       (unsigned long long)wave;
+            c_k = (int32_t)fps_tk1024_inv(wkey);
+            c_x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
+            c_y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
+            c_z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
+            fresh = 2;
+#ifdef FPS_DEBUG
+            FPS_STAMP(a2);
+            if (wave == 0 && blockIdx.x == 0) { dbg_box += a0 - s0; dbg_upd += a1 - a0; dbg_sel += a2 - a1; dbg_nact += 1; }
+#endif
+        }
+        const int par = r & 1;
+        if (lane == 0) {
+            if (fresh > 0) cand[par][wave] = FpsCand{c_k, c_x, c_y, c_z};
+            atomicMax(&cell[c3], c_packed);
+            if (wave == 0) cell[c3 == 2 ? 0 : c3 + 1] = 0ull;      // next round's cell; its readers passed the last barrier
+        }
+        fresh = fresh > 0 ? fresh - 1 : 0;
+#ifdef FPS_DEBUG
+        FPS_STAMP(s1);
+        if (act != 0) dbg_pub += s1 - a2; else dbg_idle += s1 - s0;
+#endif
+        __syncthreads();
+#ifdef FPS_DEBUG
+        FPS_STAMP(s2);
+#endif
+        // both LDS reads are issued together: every lane fetches one wave's payload, the cell picks the lane
+        const unsigned long long top = cell[c3];
+        const FpsCand w = cand[par][lane & 15];
+        const int wid = (int)__builtin_amdgcn_readfirstlane((uint32_t)top) & 15;
+        const int32_t wk = __builtin_amdgcn_readlane(w.k, wid);
+        cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.x), wid));
+        cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.y), wid));
+        cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.z), wid));
+        if (t == 0) picked[r] = wk;
+        c3 = c3 == 2 ? 0 : c3 + 1;
+#ifdef FPS_DEBUG
+        FPS_STAMP(s3);
+        acc_upd += s1 - s0; acc_bar += s2 - s1; acc_comb += s3 - s2;
+#endif
+    }
+#ifdef FPS_DEBUG
+    if (lane == 0) atomicAdd(&fps_dbg[0], n_act);
+    if (t == 0 && blockIdx.x == 0) {
+        unsigned long long t_end;
+        FPS_STAMP(t_end);
+        fps_dbg[1] = acc_upd; fps_dbg[2] = acc_bar; fps_dbg[3] = acc_comb; fps_dbg[4] = t_end - t_setup;
+        fps_dbg[5] = dbg_box; fps_dbg[6] = dbg_upd; fps_dbg[7] = dbg_sel; fps_dbg[8] = dbg_pub; fps_dbg[9] = dbg_idle;
+        fps_dbg[10] = dbg_nact;
+    }
+#endif
+
+    __syncthreads();
+    for (int i = t; i < m; i += WGS) idx[i] = picked[i];
+    if (temp) {
+#pragma unroll
+        for (int jj = 0; jj < P; ++jj)
+            if (skey[jj * 64] != 0xFFFFu) temp[fps_tk1024_inv(skey[jj * 64])] = vec_get<P>(td, jj);
+    }
+}
+
 int fps_block(int n) {
     int t = 1;
     while (t * 2 <= n && t * 2 <= 1024) t *= 2;
@@ -279,10 +663,29 @@ void launch_reg(int b, int n, int pstride, int m, const float *pts, float *temp,
                        pstride, m, pts, temp, idx, (uint32_t)(T - 1), (uint32_t)log2t);
 }
 
+template <int WGS, int P, int G>
+void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, hipStream_t s) {
+    constexpr int NP = WGS * P;
+    const size_t lds = ((size_t)4096 + (size_t)NP + (size_t)(m > NP ? m : NP)) * sizeof(uint32_t);
+    hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx);
+}
+
 int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx,
                  hipStream_t s) {
     DCLR_REQUIRE(b > 0 && n > 0 && m > 0 && pstride >= 3 && pts && idx);
-    if ((size_t)m * sizeof(int32_t) > 96 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
+    if ((size_t)m * sizeof(int32_t) > 64 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
+    static const bool plain = getenv("DCLR_FPS_PLAIN") != nullptr;             // A/B switch for measurements
+    if (!plain && n > 1024 && n <= 16384) {
+        static const int variant = getenv("DCLR_FPS_VARIANT") ? atoi(getenv("DCLR_FPS_VARIANT")) : 0;
+        if (n <= 2048) launch_pruned<1024, 2, 2>(b, n, pstride, m, pts, temp, idx, s);
+        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, s);
+        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, s);
+        else if (variant == 1) launch_pruned<512, 32, 8>(b, n, pstride, m, pts, temp, idx, s);
+        else if (variant == 2) launch_pruned<512, 32, 16>(b, n, pstride, m, pts, temp, idx, s);
+        else if (variant == 3) launch_pruned<1024, 16, 8>(b, n, pstride, m, pts, temp, idx, s);
+        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, s);
+        return dclr_launch_status();
+    }
     if (n <= 1024) launch_reg<1024, 1>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 2048) launch_reg<1024, 2>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 4096) launch_reg<1024, 4>(b, n, pstride, m, pts, temp, idx, s);

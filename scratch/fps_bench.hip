@@ -1,0 +1,38 @@
+// Diagnostic harness for the FPS kernels (not part of the product): hipcc -DFPS_DEBUG ...
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <random>
+#include <vector>
+#include "../deepclr_amd/csrc/fps.hip"
+
+int main(int argc, char **argv) {
+    const int b = 16, n = argc > 1 ? atoi(argv[1]) : 16384, m = argc > 2 ? atoi(argv[2]) : 1024, c = 4;
+    std::mt19937 rng(1);
+    std::normal_distribution<float> g(0.f, 1.f);
+    std::vector<float> h((size_t)b * n * c);
+    for (size_t i = 0; i < (size_t)b * n; ++i) {
+        h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
+    }
+    float *d; int32_t *idx;
+    hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4);
+    hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        unsigned long long zero[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(fps_dbg), zero, sizeof(zero));
+        hipEventRecord(e0);
+        int rc = dclr_fps_clouds(b, n, c, m, d, idx, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long dbg[16];
+        hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
+        const double rounds = m - 1;
+        printf("rc=%d  %.1f us | active groups/round %.2f of 64 | cycles/round wave0/cloud0: update+publish %.0f barrier-wait %.0f combine %.0f total %.0f\n",
+               rc, ms * 1e3, dbg[0] / (rounds * b), dbg[1] / rounds, dbg[2] / rounds, dbg[3] / rounds, dbg[4] / rounds);
+        const double na = dbg[10] ? (double)dbg[10] : 1.0, ni = rounds - dbg[10] > 0 ? rounds - dbg[10] : 1.0;
+        printf("   wave0/cloud0: active in %.0f of %.0f rounds; per ACTIVE round: box %.0f update %.0f select %.0f publish %.0f | per IDLE round: pre-barrier %.0f\n",
+               (double)dbg[10], rounds, dbg[5] / na, dbg[6] / na, dbg[7] / na, dbg[8] / na, dbg[9] / ni);
+    }
+    return 0;
+}

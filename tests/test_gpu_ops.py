@@ -32,6 +32,8 @@ def _cloud(kind, b, n, seed):
     ('normal', 2, 1000, 256), ('kitti', 2, 1024, 512), ('dup', 2, 1500, 512), ('grid', 2, 2048, 300),
     ('kitti', 2, 4096, 1024), ('normal', 2, 5000, 700), ('kitti', 3, 16384, 1024), ('dup', 2, 12000, 512),
     ('normal', 1, 20000, 200), ('kitti', 1, 65536, 150), ('grid', 1, 40000, 100),
+    ('normal', 2, 1025, 300), ('dup', 2, 2049, 400), ('grid', 3, 16383, 600), ('kitti', 2, 8193, 1100),
+    ('grid', 2, 9000, 9000),
 ])
 def test_fps_bit_exact(kind, b, n, m):
     xyz = _cloud(kind, b, n, seed=n + m)
