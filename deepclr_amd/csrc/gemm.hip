@@ -120,38 +120,53 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
 }
 
 // ---- FC tail: a handful of rows (one per scan pair) -------------------------------------------------
-// One wave per output column; lanes stride over K with coalesced weight reads; rows in chunks of 8.
-constexpr int FC_WAVES = 4, FC_ROWS = 8;
+// Workgroup = 4 waves x FC_COLS output columns each. The <= FC_ROWS input rows are staged in LDS once;
+// a wave streams one weight row at a time (coalesced, all loads of the row in flight) against them
+// and reduces the per-lane partial sums with DPP adds.
+constexpr int FC_WAVES = 4, FC_ROWS = 8, FC_COLS = 4, FC_MAX_K = 1024;
+
+__device__ __forceinline__ float fc_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, const float *__restrict__ x,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias, int act,
                                                            float *__restrict__ y) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = blockIdx.x * FC_WAVES + wave;
-    if (col >= n) return;
-    const float *wr = w + (size_t)col * k;
+    __shared__ float xs[FC_ROWS][FC_MAX_K];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int r0 = 0; r0 < m; r0 += FC_ROWS) {
-        float acc[FC_ROWS];
-#pragma unroll
-        for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
-        for (int kk = lane; kk < k; kk += 64) {
-            const float wv = wr[kk];
-#pragma unroll
-            for (int r = 0; r < FC_ROWS; ++r)
-                if (r0 + r < m) acc[r] = fmaf(wv, x[(size_t)(r0 + r) * k + kk], acc[r]);
+        const int rows = m - r0 < FC_ROWS ? m - r0 : FC_ROWS;
+        __syncthreads();
+        for (int e = tid; e < FC_ROWS * k; e += FC_WAVES * 64) {
+            const int r = e / k, kk = e - r * k;
+            xs[r][kk] = r < rows ? x[(size_t)(r0 + r) * k + kk] : 0.f;
         }
+        __syncthreads();
+#pragma unroll 1
+        for (int cc = 0; cc < FC_COLS; ++cc) {
+            const int col = (blockIdx.x * FC_WAVES + wave) * FC_COLS + cc;
+            if (col >= n) break;                                 // wave-uniform
+            const float *wr = w + (size_t)col * k;
+            float acc[FC_ROWS];
 #pragma unroll
-        for (int r = 0; r < FC_ROWS; ++r) {
-            float v = acc[r];
+            for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
+#pragma unroll 4
+            for (int kk = lane; kk < k; kk += 64) {
+                const float wv = wr[kk];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && r0 + r < m) {
-                v += bias ? bias[col] : 0.f;
+                for (int r = 0; r < FC_ROWS; ++r) acc[r] = fmaf(wv, xs[r][kk], acc[r]);
+            }
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < FC_ROWS; ++r) {
+                float v = fc_wave_sum(acc[r]) + bv;
                 if (act == 1) v = fmaxf(v, 0.f);
                 else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
                 else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
-                y[(size_t)(r0 + r) * n + col] = v;
+                if (lane == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
             }
         }
     }
@@ -188,7 +203,9 @@ extern "C" int dclr_linear(int m, int n, int kp, const float *x, int ldx, const 
 extern "C" int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act,
                        float *y, dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n > 0 && k > 0 && x && w && y && act >= 0 && act <= 3);
-    hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES), dim3(FC_WAVES * 64), 0,
+    if (k > FC_MAX_K) return DCLR_E_UNSUPPORTED;
+    constexpr int per_wg = FC_WAVES * FC_COLS;
+    hipLaunchKernelGGL(fc_kernel, dim3((n + per_wg - 1) / per_wg), dim3(FC_WAVES * 64), 0,
                        (hipStream_t)stream, m, n, k, x, w, bias, act, y);
     return dclr_launch_status();
 }

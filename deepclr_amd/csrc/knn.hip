@@ -5,16 +5,17 @@
 // ascending squared distance, equal distances in ascending candidate index -- the order the
 // published torch-cluster 1.5.9 GPU kernel's strict-">" insertion list yields (oracle/primitives.c).
 //
-// One wave serves a run of queries against one candidate cloud: each lane keeps CPL candidates
-// (index c*64 + lane) in registers for the whole run, so a query costs CPL distance evaluations
-// per lane plus k selection rounds; a round is a two-step DPP reduction (min distance bits, then
-// min index among equals) and only re-scans registers.
+// A workgroup stages one candidate cloud in LDS; each wave then answers a few queries: lane l owns
+// candidates c*64 + l (CPL distance evaluations per lane) and the k nearest are extracted in k
+// rounds, each a two-step DPP reduction (min distance bits, then min index among equals) over
+// registers only.
 #include "common.h"
 
 namespace {
 
 constexpr int KNN_WAVES = 4;     // waves per workgroup
-constexpr int KNN_QRUN = 8;      // queries per wave
+constexpr int KNN_QRUN = 2;      // queries per wave
+constexpr int KNN_MAX_NX = 4096; // candidates staged in LDS (3 * 4 bytes each)
 constexpr uint32_t KNN_INF = 0x7F800000u;
 
 struct KnnXyzSource {            // (clouds*n, 3) packed points
@@ -33,18 +34,25 @@ struct KnnRowSource {            // feature rows F: xyz at columns 64..66 of a 6
     }
 };
 
+// Workgroup: the candidate cloud is staged once into LDS (structure of arrays), then every wave
+// answers KNN_QRUN queries. Small register footprint -> many waves per SIMD hide the serial
+// k-round selection latency.
 template <int CPL, typename Src, typename OutFn>
-__device__ __forceinline__ void knn_run(const Src &cand, size_t cand_cloud, int nx, const Src &query,
-                                        size_t query_cloud, int ny, int q0, int q1, int k, OutFn out) {
-    const int lane = dclr_lane();
-    float px[CPL], py[CPL], pz[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int i = c * 64 + lane;
-        px[c] = py[c] = pz[c] = 0.f;
-        if (i < nx) cand.load(cand_cloud, nx, i, px[c], py[c], pz[c]);
+__device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, int nx, const Src &query,
+                                          size_t query_cloud, int ny, int k, OutFn out) {
+    extern __shared__ float knn_lds[];                      // x[nxp] y[nxp] z[nxp], nxp = 64 * CPL
+    constexpr int NXP = 64 * CPL;
+    float *sx = knn_lds, *sy = knn_lds + NXP, *sz = knn_lds + 2 * NXP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < NXP; i += KNN_WAVES * 64) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < nx) cand.load(cand_cloud, nx, i, x, y, z);
+        sx[i] = x; sy[i] = y; sz[i] = z;
     }
-    for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
+#pragma unroll 1
+    for (int q = q0; q < q0 + KNN_QRUN && q < ny; ++q) {
         float qx, qy, qz;
         query.load(query_cloud, ny, q, qx, qy, qz);          // wave-uniform
         uint32_t d[CPL];
@@ -52,8 +60,9 @@ __device__ __forceinline__ void knn_run(const Src &cand, size_t cand_cloud, int 
         for (int c = 0; c < CPL; ++c) {
             const int i = c * 64 + lane;
             // (candidate - query), accumulated x,y,z: the published kernel's order
-            d[c] = i < nx ? __float_as_uint(dclr_sqdist(px[c], py[c], pz[c], qx, qy, qz)) : KNN_INF;
+            d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
         }
+#pragma unroll 1
         for (int s = 0; s < k; ++s) {
             uint32_t lmin = d[0];
             int lc = 0;
@@ -80,13 +89,9 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_xyz_kernel(int nx, int ny,
                                                                  const float *__restrict__ y,
                                                                  int64_t *__restrict__ row,
                                                                  int64_t *__restrict__ col) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t bi = blockIdx.y;
-    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
-    const int q1 = q0 + KNN_QRUN < ny ? q0 + KNN_QRUN : ny;
-    if (q0 >= ny) return;
     KnnXyzSource cs{x}, qs{y};
-    knn_run<CPL>(cs, bi, nx, qs, bi, ny, q0, q1, k, [&](int q, int s, int ci) {
+    knn_block<CPL>(cs, bi, nx, qs, bi, ny, k, [&](int q, int s, int ci) {
         const size_t gq = bi * ny + q;
         row[gq * k + s] = ci < 0 ? -1 : (int64_t)gq;
         col[gq * k + s] = ci < 0 ? -1 : (int64_t)(bi * nx + ci);
@@ -97,13 +102,9 @@ template <int CPL>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int pairs, int npoint, int k,
                                                                   const float *__restrict__ f_rows,
                                                                   int32_t *__restrict__ knn_idx) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t bi = blockIdx.y;
-    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
-    const int q1 = q0 + KNN_QRUN < npoint ? q0 + KNN_QRUN : npoint;
-    if (q0 >= npoint) return;
     KnnRowSource src{f_rows};
-    knn_run<CPL>(src, bi + pairs, npoint, src, bi, npoint, q0, q1, k, [&](int q, int s, int ci) {
+    knn_block<CPL>(src, bi + pairs, npoint, src, bi, npoint, k, [&](int q, int s, int ci) {
         knn_idx[(bi * npoint + q) * k + s] = ci;
     });
 }
@@ -116,7 +117,7 @@ int knn_dispatch(int nx, Args... args) {
     if (nx <= 512) return Launcher<8>::go(args...);
     if (nx <= 1024) return Launcher<16>::go(args...);
     if (nx <= 2048) return Launcher<32>::go(args...);
-    if (nx <= 4096) return Launcher<64>::go(args...);
+    if (nx <= KNN_MAX_NX) return Launcher<64>::go(args...);
     return DCLR_E_UNSUPPORTED;
 }
 
@@ -126,7 +127,7 @@ struct XyzLauncher {
                   hipStream_t s) {
         const int per_wg = KNN_WAVES * KNN_QRUN;
         hipLaunchKernelGGL((knn_xyz_kernel<CPL>), dim3((ny + per_wg - 1) / per_wg, b), dim3(KNN_WAVES * 64),
-                           0, s, nx, ny, k, x, y, row, col);
+                           (size_t)3 * 64 * CPL * sizeof(float), s, nx, ny, k, x, y, row, col);
         return dclr_launch_status();
     }
 };
@@ -136,7 +137,8 @@ struct RowsLauncher {
     static int go(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx, hipStream_t s) {
         const int per_wg = KNN_WAVES * KNN_QRUN;
         hipLaunchKernelGGL((knn_rows_kernel<CPL>), dim3((npoint + per_wg - 1) / per_wg, pairs),
-                           dim3(KNN_WAVES * 64), 0, s, pairs, npoint, k, f_rows, knn_idx);
+                           dim3(KNN_WAVES * 64), (size_t)3 * 64 * CPL * sizeof(float), s, pairs, npoint, k, f_rows,
+                           knn_idx);
         return dclr_launch_status();
     }
 };

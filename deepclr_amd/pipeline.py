@@ -1,0 +1,81 @@
+"""Throughput runner: overlap the serial sampling stage with the dense stages.
+
+Furthest point sampling is one workgroup per cloud -- 2B of the 256 CUs for a batch of B scan pairs --
+and takes about as long as all other stages together, which in turn cannot start without its result.
+For a STREAM of batches the dependency is only within a batch, so the runner issues sampling for
+batches i+1 .. i+depth on side HIP streams while set abstraction, flow embedding and the pose head
+of batch i run on the main stream (the reference never batches or pipelines: one pair per call,
+/root/reference/deepclr/models/base.py:118-120, scripts/inference.py:100-104).
+"""
+from collections import deque
+from typing import Deque, Iterable, Iterator, Optional, Tuple
+
+import torch
+
+from .models.deepclr import DeepCLR
+
+
+class PipelinedForward:
+    def __init__(self, model: DeepCLR, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self._model = model.eval()
+        self.depth = depth
+        self._streams = [torch.cuda.Stream() for _ in range(depth)]
+        self._next_stream = 0
+        self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
+
+    def prefetch(self, x: torch.Tensor) -> None:
+        """Start sampling for `x` (2B, N, C) on the next side stream."""
+        main = torch.cuda.current_stream()
+        side = self._streams[self._next_stream]
+        self._next_stream = (self._next_stream + 1) % self.depth
+        side.wait_stream(main)                               # x (and anything producing it) is ready
+        with torch.cuda.stream(side):
+            idx = self._model.sample(x)
+            done = torch.cuda.Event()
+            done.record(side)
+        x.record_stream(side)
+        self._pending.append((x, idx, done))
+
+    def in_flight(self) -> int:
+        return len(self._pending)
+
+    def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = ()) -> torch.Tensor:
+        """Pose outputs (B, label_dim) for batch `x`. `upcoming` lists later batches (oldest first) that are
+        not yet being sampled; as many as fit the pipeline depth are started before this batch's dense
+        stages are enqueued, so they run beside them."""
+        main = torch.cuda.current_stream()
+        idx = None
+        if self._pending and self._pending[0][0] is x:
+            _, idx, done = self._pending.popleft()
+            main.wait_event(done)
+            idx.record_stream(main)
+        for nxt in upcoming:
+            if len(self._pending) >= self.depth:
+                break
+            self.prefetch(nxt)
+        with torch.no_grad():
+            f_rows = self._model.cloud_feature_rows(x, idx)
+            return self._model.merge_rows(f_rows, x.shape[0] // 2)
+
+    def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
+        it = iter(batches)
+        window: Deque[torch.Tensor] = deque()
+
+        def refill():
+            while len(window) < self.depth + 1:
+                nxt = next(it, None)
+                if nxt is None:
+                    break
+                window.append(nxt)
+
+        refill()
+        if not window:
+            return
+        self.prefetch(window[0])
+        while window:
+            cur = window.popleft()
+            refill()
+            started = self.in_flight()
+            yield self.step(cur, list(window)[started:])

@@ -81,11 +81,17 @@ class PointnetSAModuleMSG(nn.Module):
                     for stack in self.mlps]
         return self._cache.get(list(self.parameters()), build)
 
-    def forward_rows(self, clouds: torch.Tensor) -> torch.Tensor:
-        """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68)."""
+    def sample(self, clouds: torch.Tensor) -> torch.Tensor:
+        """Furthest point sampling only: clouds (B, N, C) -> (B, npoint) int32 (the serial stage; the
+        pipelined runner issues it one batch ahead on a side stream)."""
         if clouds.shape[2] != 3 + self._in_feat:
             raise RuntimeError("expected {} columns per point, got {}".format(3 + self._in_feat, clouds.shape[2]))
-        fps_idx = ops.fps_clouds(clouds, self.npoint)
+        return ops.fps_clouds(clouds, self.npoint)
+
+    def forward_rows(self, clouds: torch.Tensor, fps_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68)."""
+        if fps_idx is None:
+            fps_idx = self.sample(clouds)
         return ops.sa_msg_fused(clouds, fps_idx, self.radii, self.nsamples, self.packed_mlps())
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
