@@ -28,6 +28,25 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(int n_out, int k_in, c
     packed[e] = v;
 }
 
+// Same, for the 16x16x4 MFMA layout (mma.h): 16-column tiles, K groups of 16.
+__global__ __launch_bounds__(256) void pack_weight16_kernel(int n_out, int k_in, const float *__restrict__ w,
+                                                            const int32_t *__restrict__ kmap, int kp, int np,
+                                                            float *__restrict__ packed) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)np * kp) return;
+    const int q = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    const size_t grp = e >> 8;                 // ntile * KG16 + g
+    const int kg = kp / 16;
+    const int g = (int)(grp % kg), ntile = (int)(grp / kg);
+    const int n = ntile * 16 + (lane & 15);
+    const int k = g * 16 + 4 * (lane >> 4) + q;
+    int col = kmap ? kmap[k] : (k < k_in ? k : -1);
+    float v = 0.f;
+    if (n < n_out && col >= 0 && col < k_in) v = w[(size_t)n * k_in + col];
+    packed[e] = v;
+}
+
 // ---- Y = act(X W^T + b) ----------------------------------------------------------------------------
 // Workgroup: 64 rows x 128 columns, 4 waves; wave w owns column tile w (32 columns) and both 32-row
 // tiles. X is staged through LDS in 32-wide K chunks (double buffered, one barrier per chunk);
@@ -180,6 +199,16 @@ extern "C" int dclr_pack_weight(int n_out, int k_in, const float *w, const int32
     DCLR_REQUIRE(kp % 8 == 0 && np % 32 == 0 && np >= n_out && (kmap || kp >= k_in));
     const size_t total = (size_t)np * kp;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, n_out, k_in, w, kmap, kp, np, packed);
+    return dclr_launch_status();
+}
+
+extern "C" int dclr_pack_weight16(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int np,
+                                  float *packed, dclr_stream_t stream) {
+    DCLR_REQUIRE(n_out > 0 && k_in > 0 && w && packed && kp > 0 && np > 0);
+    DCLR_REQUIRE(kp % 16 == 0 && np % 16 == 0 && np >= n_out && (kmap || kp >= k_in));
+    const size_t total = (size_t)np * kp;
+    hipLaunchKernelGGL(pack_weight16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, n_out, k_in, w, kmap, kp, np, packed);
     return dclr_launch_status();
 }

@@ -54,3 +54,32 @@ __device__ __forceinline__ void dclr_mma_group(dclr_f32x16 (&acc)[MT][NT], const
 
 // Row of accumulator register r for lane-half h inside a 32-row tile.
 __device__ __forceinline__ int dclr_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- 16x16x4 variant (v_mfma_f32_16x16x4_f32: 32-cycle issue, same FLOP rate, 4 accumulator registers).
+// Operand maps (lane l, r/c = l & 15, kq = l >> 4):  A[r][kq]  B[kq][c]  C/D: column c, row 4*kq + reg.
+// K is consumed in groups of 16: MFMA q (0..3) multiplies k = 16*g + 4*kq + q.
+//   activations  X[row][16g + 4kq .. +3]                       (ds_read_b128)
+//   weights      packed16[(ntile*KG16 + g)*64 + lane] (float4) (one coalesced 1 KiB load per wave)
+typedef float dclr_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int NT>
+__device__ __forceinline__ void dclr_mma16_group(dclr_f32x4 (&acc)[MT][NT], const float *a_lds, int stride, int g,
+                                                 const float4 *w_lane, int ntile_stride) {
+    float4 b[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) b[u] = w_lane[(size_t)u * ntile_stride];
+    float4 a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 16 * stride + 16 * g);
+    // q outermost: back-to-back MFMAs hit different accumulators (dependent latency 40 > issue 32 cycles)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float av = q == 0 ? a[t].x : (q == 1 ? a[t].y : (q == 2 ? a[t].z : a[t].w));
+                const float bw = q == 0 ? b[u].x : (q == 1 ? b[u].y : (q == 2 ? b[u].z : b[u].w));
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[t][u], 0, 0, 0);
+            }
+}

@@ -29,6 +29,7 @@ SIGNATURES = {
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_channels_to_rows': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],
+    'dclr_pack_weight16': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_linear': [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p],
     'dclr_knn_rows': [_i, _i, _i, _p, _p, _p],
     'dclr_flow_embedding_fused': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -131,8 +131,8 @@ class MotionEmbeddingBase(nn.Module):
             return {
                 'w1a': w1[:, :d].contiguous(), 'b1': b1.detach().contiguous(),
                 'wt': ops.pack_weight(w_t.contiguous(), FEAT, kmap), 'ws': ops.pack_weight(w_s.contiguous(), FEAT, kmap),
-                'w2p': ops.pack_weight(w2, 128), 'b2': b2.detach().contiguous(),
-                'w3p': ops.pack_weight(w3, 128), 'b3': b3.detach().contiguous(),
+                'w2p': ops.pack_weight(w2, 128, tile16=True), 'b2': b2.detach().contiguous(),
+                'w3p': ops.pack_weight(w3, 128, tile16=True), 'b3': b3.detach().contiguous(),
             }
         return self._cache.get(list(self.parameters()), build)
 

@@ -170,10 +170,17 @@ def channels_to_rows(channels: torch.Tensor, stride: int) -> torch.Tensor:
     return rows
 
 
-def pack_weight(w: torch.Tensor, kp: int, kmap: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Row-major (n_out, k_in) -> MFMA fragment order, K padded to kp, N padded to a multiple of 32."""
+def pack_weight(w: torch.Tensor, kp: int, kmap: Optional[torch.Tensor] = None, tile16: bool = False) -> torch.Tensor:
+    """Row-major (n_out, k_in) -> MFMA fragment order, K padded to kp, N padded to a multiple of 32
+    (tile16: the 16-column layout of the fused flow-embedding kernel, N padded to a multiple of 16)."""
     w = lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w')
     n_out, k_in = w.shape
+    if tile16:
+        np_ = (n_out + 15) // 16 * 16
+        packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)
+        _call('dclr_pack_weight16', 'pack_weight16', n_out, k_in, w.data_ptr(), lib.ptr(kmap), kp, np_,
+              packed.data_ptr(), lib.stream_ptr())
+        return packed
     np_ = (n_out + 31) // 32 * 32
     packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)
     if kmap is not None:

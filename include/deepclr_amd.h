@@ -125,6 +125,11 @@ int dclr_channels_to_rows(int b, int npoint, int nfeat, int xyz_col, int stride,
 int dclr_pack_weight(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int np,
                      float *packed, dclr_stream_t stream);
 
+/* The same for the fused flow-embedding kernel's 16-column tile layout (v_mfma_f32_16x16x4_f32):
+ * kp multiple of 16, np multiple of 16. */
+int dclr_pack_weight16(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int np,
+                       float *packed, dclr_stream_t stream);
+
 /* Y = act(X * W^T + bias): X rows (m, ldx) using its first kp columns, packed W (np, kp), bias (n) or
  * NULL, Y rows (m, ldy) first n columns. relu != 0 applies max(.,0). Requires m % 64 == 0,
  * ldx % 4 == 0 and 16-byte aligned X. If colmax != NULL nothing is written to Y; instead
@@ -145,7 +150,8 @@ int dclr_knn_rows(int pairs, int npoint, int k, const float *f_rows, int32_t *kn
  * pt/ps (pairs*npoint,128) hold W1b*feat_t and W1c*feat_s (dclr_linear, no bias, no relu).
  * Per template point: gather its k neighbours, h1 = relu(pt + ps[nb] + W1a*pos_diff + b1),
  * two MFMA layers, zero rows with |pos_diff| >= radius (radius <= 0 disables), max over k.
- * w1a (128,3) row-major, b1 (128); w2p/w3p packed (128,128)/(256,128); out rows E. k <= 32. */
+ * w1a (128,3) row-major, b1 (128); w2p/w3p packed with dclr_pack_weight16 (128,128)/(256,128);
+ * out rows E. k <= 32. */
 int dclr_flow_embedding_fused(int pairs, int npoint, int k, float radius, const float *f_rows,
                               const int32_t *knn_idx, const float *pt, const float *ps,
                               const float *w1a, const float *b1, const float *w2p, const float *b2,
