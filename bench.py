@@ -39,16 +39,26 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
 class LaunchTimer:
     """HIP events around every library launch, on the stream the kernel is enqueued on."""
 
+    SAMPLE_EVERY = 4       # bracket the launches of every 4th step only: the events themselves cost ~10 %
+
     def __init__(self):
         self.spans = []
         self.main_stream = torch.cuda.current_stream().cuda_stream
+        self.step = 0
+
+    def next_step(self):
+        self.step += 1
 
     def begin(self, name):
+        if self.step % self.SAMPLE_EVERY != 0:
+            return None
         start = torch.cuda.Event(enable_timing=True)
         start.record()
         return (name, start, torch.cuda.current_stream().cuda_stream == self.main_stream)
 
     def end(self, token):
+        if token is None:
+            return
         stop = torch.cuda.Event(enable_timing=True)
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
@@ -166,6 +176,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
+        if timer is not None:
+            timer.next_step()
     fence()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
@@ -181,6 +193,7 @@ def main():
         rooflines = None
         if timer is not None:
             kernels = timer.summary()
+            sampled_steps = len(range(0, args.steps, LaunchTimer.SAMPLE_EVERY))
 
             def roof(name):
                 bound, units = algorithmic_work(name, cfg, PAIRS_PER_GPU, POINTS)
@@ -191,7 +204,7 @@ def main():
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
                 return {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
                         'frac': achieved / peak, 'traffic': None, 'avg_us': kernels[name]['avg_us'],
-                        'share_of_step': kernels[name]['total_ms'] / (elapsed * 1e3),
+                        'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
                         'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
 
             # dominant kernel = largest total time on the stream that bounds the step (the main one);

@@ -54,22 +54,26 @@ __global__ __launch_bounds__(256) void pack_weight16_kernel(int n_out, int k_in,
 constexpr int LIN_BM = 64, LIN_BK = 32, LIN_WAVES = 4;
 constexpr int LIN_STRIDE = dclr_lds_stride(LIN_BK);       // 36 floats
 
+// MT = 32-row tiles per workgroup (1 or 2): layers whose grid would otherwise leave CUs with a single
+// workgroup (nothing to overlap its barriers and load latencies with) use the 32-row variant.
+template <int MT>
 __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, int kp, const float *__restrict__ x,
                                                                 int ldx, const float4 *__restrict__ wp,
                                                                 const float *__restrict__ bias, int relu,
                                                                 float *__restrict__ y, int ldy,
                                                                 float *__restrict__ colmax, int rows_per_group) {
-    __shared__ __attribute__((aligned(16))) float tile[2][LIN_BM * LIN_STRIDE];
+    constexpr int BM = 32 * MT;
+    __shared__ __attribute__((aligned(16))) float tile[2][BM * LIN_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int m0 = blockIdx.x * LIN_BM;
+    const int m0 = blockIdx.x * BM;
     const int ntile = blockIdx.y * LIN_WAVES + wave;
     const int n_tiles = (n + 31) / 32;
     const bool active = ntile < n_tiles;                  // wave-uniform
     const int kg_total = kp / 8;
     const int n_chunks = (kp + LIN_BK - 1) / LIN_BK;
 
-    // staging role: thread -> (row, 16-byte column) of the 64 x 32 chunk, two rows per thread
+    // staging role: thread -> (row, 16-byte column) of the BM x 32 chunk, MT rows per thread
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     const float *xs0 = x + (size_t)(m0 + srow) * ldx + scol;
     const float *xs1 = xs0 + (size_t)32 * ldx;
@@ -79,17 +83,17 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
         r0 = r1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kc < kp) {
             r0 = *reinterpret_cast<const float4 *>(xs0 + chunk * LIN_BK);
-            r1 = *reinterpret_cast<const float4 *>(xs1 + chunk * LIN_BK);
+            if constexpr (MT == 2) r1 = *reinterpret_cast<const float4 *>(xs1 + chunk * LIN_BK);
         }
     };
     auto stash = [&](int buf, const float4 &r0, const float4 &r1) {
         *reinterpret_cast<float4 *>(&tile[buf][srow * LIN_STRIDE + scol]) = r0;
-        *reinterpret_cast<float4 *>(&tile[buf][(srow + 32) * LIN_STRIDE + scol]) = r1;
+        if constexpr (MT == 2) *reinterpret_cast<float4 *>(&tile[buf][(srow + 32) * LIN_STRIDE + scol]) = r1;
     };
 
-    dclr_f32x16 acc[2][1];
-    acc[0][0] = dclr_zero16();
-    acc[1][0] = dclr_zero16();
+    dclr_f32x16 acc[MT][1];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t][0] = dclr_zero16();
 
     const float4 *w_lane = wp + ((size_t)(active ? ntile : 0) * kg_total) * 64 + lane;
 
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
             const int g1 = g0 + LIN_BK / 8 < kg_total ? g0 + LIN_BK / 8 : kg_total;
             const float *a_lds = &tile[buf][j * LIN_STRIDE + 4 * h];
             for (int g = g0; g < g1; ++g)
-                dclr_mma_group<2, 1>(acc, a_lds, LIN_STRIDE, g - g0, w_lane + (size_t)g * 64, 0);
+                dclr_mma_group<MT, 1>(acc, a_lds, LIN_STRIDE, g - g0, w_lane + (size_t)g * 64, 0);
         }
         if (c + 1 < n_chunks) stash(buf ^ 1, r0, r1);
         __syncthreads();
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
     if (colmax) {
         float mx = 0.f;                                   // relu is required: values >= 0
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][0][r] + bv);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
         return;
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + t * 32 + dclr_acc_row(r, h);
@@ -139,10 +143,11 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
 }
 
 // ---- FC tail: a handful of rows (one per scan pair) -------------------------------------------------
-// Workgroup = 4 waves x FC_COLS output columns each. The <= FC_ROWS input rows are staged in LDS once;
-// a wave streams one weight row at a time (coalesced, all loads of the row in flight) against them
-// and reduces the per-lane partial sums with DPP adds.
-constexpr int FC_WAVES = 4, FC_ROWS = 8, FC_COLS = 4, FC_MAX_K = 1024;
+// One wave per output column, 4 columns per workgroup. The <= FC_ROWS input rows are staged in LDS
+// once per workgroup; a wave keeps the whole weight row in flight (K/64 coalesced loads issued back
+// to back -- a serial load-use loop costs one L2 round trip per 64 weights) and reduces the per-lane
+// partial sums with DPP adds.
+constexpr int FC_WAVES = 4, FC_ROWS = 8, FC_MAX_K = 1024, FC_CHUNKS = FC_MAX_K / 64;
 
 __device__ __forceinline__ float fc_wave_sum(float v) {
 #pragma unroll
@@ -156,37 +161,40 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, 
                                                            float *__restrict__ y) {
     __shared__ float xs[FC_ROWS][FC_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = blockIdx.x * FC_WAVES + wave;
+    const bool live = col < n;                                       // wave-uniform
+    float wv[FC_CHUNKS];
+    if (live) {
+        const float *wr = w + (size_t)col * k;
+#pragma unroll
+        for (int c = 0; c < FC_CHUNKS; ++c) wv[c] = c * 64 + lane < k ? wr[c * 64 + lane] : 0.f;
+    }
+    const float bv = (live && bias) ? bias[col] : 0.f;
     for (int r0 = 0; r0 < m; r0 += FC_ROWS) {
         const int rows = m - r0 < FC_ROWS ? m - r0 : FC_ROWS;
         __syncthreads();
-        for (int e = tid; e < FC_ROWS * k; e += FC_WAVES * 64) {
-            const int r = e / k, kk = e - r * k;
-            xs[r][kk] = r < rows ? x[(size_t)(r0 + r) * k + kk] : 0.f;
-        }
+        for (int r = 0; r < FC_ROWS; ++r)
+            for (int kk = tid; kk < k; kk += FC_WAVES * 64)
+                xs[r][kk] = r < rows ? x[(size_t)(r0 + r) * k + kk] : 0.f;
         __syncthreads();
-#pragma unroll 1
-        for (int cc = 0; cc < FC_COLS; ++cc) {
-            const int col = (blockIdx.x * FC_WAVES + wave) * FC_COLS + cc;
-            if (col >= n) break;                                 // wave-uniform
-            const float *wr = w + (size_t)col * k;
-            float acc[FC_ROWS];
+        if (!live) continue;
+        float acc[FC_ROWS];
 #pragma unroll
-            for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll 4
-            for (int kk = lane; kk < k; kk += 64) {
-                const float wv = wr[kk];
+        for (int r = 0; r < FC_ROWS; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < FC_ROWS; ++r) acc[r] = fmaf(wv, xs[r][kk], acc[r]);
+        for (int c = 0; c < FC_CHUNKS; ++c) {
+            if (c * 64 < k) {                                        // uniform
+#pragma unroll
+                for (int r = 0; r < FC_ROWS; ++r) acc[r] = fmaf(wv[c], xs[r][c * 64 + lane < k ? c * 64 + lane : 0], acc[r]);
             }
-            const float bv = bias ? bias[col] : 0.f;
+        }
 #pragma unroll
-            for (int r = 0; r < FC_ROWS; ++r) {
-                float v = fc_wave_sum(acc[r]) + bv;
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
-                else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
-                if (lane == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
-            }
+        for (int r = 0; r < FC_ROWS; ++r) {
+            float v = fc_wave_sum(acc[r]) + bv;
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
+            else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
+            if (lane == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
         }
     }
 }
@@ -222,10 +230,15 @@ extern "C" int dclr_linear(int m, int n, int kp, const float *x, int ldx, const 
     if (colmax) DCLR_REQUIRE(relu && rows_per_group > 0 && rows_per_group % LIN_BM == 0 && m % rows_per_group == 0);
     else DCLR_REQUIRE(ldy >= n);
     const int n_tiles = (n + 31) / 32;
-    dim3 grid(m / LIN_BM, (n_tiles + LIN_WAVES - 1) / LIN_WAVES);
-    DCLR_REQUIRE(grid.y <= 65535);
-    hipLaunchKernelGGL(linear_kernel, grid, dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n, kp, x, ldx,
-                       reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax, rows_per_group);
+    const unsigned gy = (n_tiles + LIN_WAVES - 1) / LIN_WAVES;
+    DCLR_REQUIRE(gy <= 65535);
+    if ((size_t)(m / LIN_BM) * gy < 1024)       // fewer than 4 workgroups per CU: halve the row tile
+        hipLaunchKernelGGL((linear_kernel<1>), dim3(m / 32, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n, kp,
+                           x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax, rows_per_group);
+    else
+        hipLaunchKernelGGL((linear_kernel<2>), dim3(m / LIN_BM, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n,
+                           kp, x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax,
+                           rows_per_group);
     return dclr_launch_status();
 }
 
@@ -233,8 +246,7 @@ extern "C" int dclr_fc(int m, int n, int k, const float *x, const float *w, cons
                        float *y, dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n > 0 && k > 0 && x && w && y && act >= 0 && act <= 3);
     if (k > FC_MAX_K) return DCLR_E_UNSUPPORTED;
-    constexpr int per_wg = FC_WAVES * FC_COLS;
-    hipLaunchKernelGGL(fc_kernel, dim3((n + per_wg - 1) / per_wg), dim3(FC_WAVES * 64), 0,
+    hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES), dim3(FC_WAVES * 64), 0,
                        (hipStream_t)stream, m, n, k, x, w, bias, act, y);
     return dclr_launch_status();
 }
