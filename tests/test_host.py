@@ -1,0 +1,121 @@
+"""CPU tests of the host layer: config, labels, state_dict layout, C-ABI surface, failure behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from deepclr_amd import lib, synthetic
+from deepclr_amd.config import load_model_config, model_config_from_dict
+from deepclr_amd.labels import LabelType
+from deepclr_amd.models import build_model, load_trained_model, ModelInferenceHelper, ModelType
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/deepclr_amd.h <-> libdeepclr_amd.so <-> lib.SIGNATURES agree (no compute call: no GPU here)."""
+    header = open(os.path.join(ROOT, 'include', 'deepclr_amd.h')).read()
+    declared = set(re.findall(r'\b(dclr_[a-z0-9_]+)\s*\(', header)) - {'dclr_stream_t'}
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    assert os.path.exists(lib.LIB_PATH), 'run python -m deepclr_amd.build'
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert lib.load().dclr_version() >= 1
+    assert lib.load().dclr_error_string(-1).decode().startswith('invalid argument')
+    assert lib.load().dclr_error_string(-2).decode().startswith('configuration not supported')
+
+
+def test_state_dict_layout_matches_reference():
+    """Key names / shapes of SURVEY.md section 8a-11 (verified against the reference's own modules by
+    tests/golden/make_golden.py, which loads the same synthetic state_dict with strict=True)."""
+    for kind, n_params in (('kitti', 1_778_312), ('modelnet', 1_778_280)):
+        cfg = synthetic.model_cfg(kind)
+        model = build_model(model_config_from_dict(cfg))
+        sd = model.state_dict()
+        shapes = synthetic.state_dict_shapes(cfg)
+        assert list(sd.keys()) == list(shapes.keys())
+        assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+        assert sum(v.numel() for v in sd.values()) == n_params
+        out_bias = sd['_merge_layers.1.output.bias']
+        assert out_bias.tolist() == [1.0, 0, 0, 0, 0, 0, 0, 0]           # LabelType.bias for dual quaternions
+        assert float(sd['_merge_layers.1.conv._sequential.0._sequential.0.bias'].abs().max()) == 0.0
+    assert model.get_input_dim() == 3 and not model.has_loss() and model.get_loss_weights() == {}
+
+
+def test_load_model_config_and_trained_model(tmp_path):
+    cfg_d = synthetic.model_cfg('kitti')
+    cfg_d['params']['loss'] = {'name': 'TransformLoss', 'params': {'p': 2, 'sx': 1, 'sq': 1}}   # as tests/model/deepclr.yaml
+    path = tmp_path / 'model_config.yaml'
+    path.write_text(yaml.safe_dump(cfg_d))
+    sd = synthetic.random_state_dict(cfg_d, 1)
+    weights = tmp_path / 'weights.tar'
+    torch.save(sd, weights)
+    cfg = load_model_config(str(path), str(weights))
+    assert cfg.label_type is LabelType.POSE3D_DUAL_QUAT and cfg.model_type is ModelType.DEEPCLR
+    assert cfg.params.cloud_features.name == 'SetAbstraction' and cfg.weights == str(weights)
+    model = load_trained_model(cfg)
+    assert model.has_loss()
+    for k, v in sd.items():
+        assert torch.equal(model.state_dict()[k], v)
+    with pytest.raises(RuntimeError):
+        model_config_from_dict({**synthetic.model_cfg('kitti'), 'point_dim': 5})
+
+
+def test_unsupported_configurations_fail_loudly():
+    base = synthetic.model_cfg('kitti')
+    for mutate in (lambda c: c['params'].update(batch_norm=True),
+                   lambda c: c['params']['merge']['params'].update(k=0),
+                   lambda c: c['params']['merge']['params'].update(k=40),
+                   lambda c: c['params']['merge']['params'].update(mlp=[64, 64, 128]),
+                   lambda c: c['params']['cloud_features']['params'].update(mlps=[[[32, 32, 64], [16, 16, 32]]])):
+        cfg = synthetic.model_cfg('kitti')
+        mutate(cfg)
+        with pytest.raises(NotImplementedError):
+            build_model(model_config_from_dict(cfg))
+    assert base == synthetic.model_cfg('kitti')
+
+
+def test_no_cpu_fallback():
+    model = build_model(model_config_from_dict(synthetic.model_cfg('kitti')))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(2, 64, 4))
+    helper = ModelInferenceHelper(model)
+    with pytest.raises(RuntimeError):
+        helper.predict(torch.zeros(64, 3), torch.zeros(64, 4))          # too few columns
+    with pytest.raises(RuntimeError):
+        helper.predict(torch.zeros(64, 4))                              # template missing
+
+
+def test_stack_subsamples_larger_cloud():
+    a, b = torch.rand(10, 4), torch.rand(7, 4)
+    s = ModelInferenceHelper.stack(a, b)
+    assert s.shape == (2, 7, 4) and torch.equal(s[1], b)
+    rows = {tuple(r.tolist()) for r in a}
+    assert all(tuple(r.tolist()) in rows for r in s[0])
+
+
+def test_label_types():
+    lt = LabelType.create('pose3d_dual_quat')
+    assert lt.dim == 8 and len(lt.names) == 8 and lt.bias[0] == 1.0
+    ident = lt.to_matrix(np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32))
+    assert np.abs(ident - np.eye(4)).max() < 1e-7
+    q = LabelType.POSE3D_QUAT
+    m = q.to_matrix(np.array([1.0, 2.0, 3.0, 0.5, 0.5, 0.5, 0.5]))
+    assert np.allclose(m[:3, 3], [1, 2, 3]) and np.allclose(m[:3, :3] @ m[:3, :3].T, np.eye(3))
+    assert np.allclose(q.to_matrix(q.from_matrix(m)), m)
+    with pytest.raises(NotImplementedError):
+        LabelType.POSE3D_EULER.to_matrix(np.zeros(6))
+
+
+def test_synthetic_inputs_are_deterministic():
+    a = synthetic.make_batch('kitti', 2, 128)
+    b = synthetic.make_batch('kitti', 2, 128)
+    assert a.shape == (4, 128, 4) and a.dtype == np.float32 and np.array_equal(a, b)
+    assert not np.array_equal(a[0], synthetic.make_batch('kitti', 1, 128, first_pair=1)[0])
+    m = synthetic.make_batch('modelnet', 1, 64)
+    assert m.shape == (2, 64, 3) and np.abs(m).max() < 1.5
