@@ -123,7 +123,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-launch-timer', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--no-overlap', action='store_true', help='run sampling in line instead of batches ahead')
-    ap.add_argument('--depth', type=int, default=2, help='batches whose sampling runs ahead on side streams')
+    ap.add_argument('--depth', type=int, default=3, help='batches whose sampling runs ahead on side streams')
+    ap.add_argument('--ahead', default='features', choices=['sample', 'features'], help='stages run ahead')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -147,7 +148,7 @@ def main():
     x = torch.from_numpy(synthetic.make_batch('kitti', PAIRS_PER_GPU, POINTS, first_pair=rank * PAIRS_PER_GPU)).to(dev)
     gathered = torch.empty(world * PAIRS_PER_GPU, 8, device=dev) if world > 1 else None
 
-    runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth)
+    runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead)
     if runner is not None:
         for _ in range(args.depth):
             runner.prefetch(x)

@@ -97,8 +97,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow_kernel(int pairs, in
 #pragma unroll
         for (int t = 0; t < T; ++t) { acc[t][0] = 0.f; acc[t][1] = 0.f; }
         const float4 *wl = w2p + (size_t)(2 * wave) * FL_KG * 64 + lane;
-#pragma unroll 2
-        for (int g = 0; g < FL_KG; ++g) dclr_mma16_group<T, 2>(acc, a_lds, FL_STRIDE, g, wl + g * 64, FL_KG * 64);
+        dclr_mma16_panel<T, 2>(acc, a_lds, FL_STRIDE, FL_KG, wl, FL_KG * 64);
         __syncthreads();                                   // every wave has consumed layer-1 rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -122,8 +121,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow_kernel(int pairs, in
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[t][u] = 0.f;
         const float4 *wl = w3p + (size_t)(4 * wave) * FL_KG * 64 + lane;
-#pragma unroll 2
-        for (int g = 0; g < FL_KG; ++g) dclr_mma16_group<T, 4>(acc, a_lds, FL_STRIDE, g, wl + g * 64, FL_KG * 64);
+        dclr_mma16_panel<T, 4>(acc, a_lds, FL_STRIDE, FL_KG, wl, FL_KG * 64);
         const uint32_t vb = vbits[kq];                     // lane-quarter kq holds template point kq
         const size_t gp = g0 + kq;
 #pragma unroll

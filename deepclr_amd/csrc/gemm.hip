@@ -109,8 +109,7 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
             const int g0 = c * (LIN_BK / 8);
             const int g1 = g0 + LIN_BK / 8 < kg_total ? g0 + LIN_BK / 8 : kg_total;
             const float *a_lds = &tile[buf][j * LIN_STRIDE + 4 * h];
-            for (int g = g0; g < g1; ++g)
-                dclr_mma_group<MT, 1>(acc, a_lds, LIN_STRIDE, g - g0, w_lane + (size_t)g * 64, 0);
+            dclr_mma_panel<MT, 1>(acc, a_lds, LIN_STRIDE, 0, g1 - g0, w_lane + (size_t)g0 * 64, 0);
         }
         if (c + 1 < n_chunks) stash(buf ^ 1, r0, r1);
         __syncthreads();

@@ -16,11 +16,16 @@ from .models.deepclr import DeepCLR
 
 
 class PipelinedForward:
-    def __init__(self, model: DeepCLR, depth: int = 2):
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features'):
+        """ahead: what runs on the side streams -- 'sample' (sampling only) or 'features' (sampling + set
+        abstraction; the dense kernels of two batches then overlap and fill each other's tails)."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
+        if ahead not in ('sample', 'features'):
+            raise ValueError("ahead must be 'sample' or 'features'")
         self._model = model.eval()
         self.depth = depth
+        self._ahead = ahead
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
@@ -31,12 +36,14 @@ class PipelinedForward:
         side = self._streams[self._next_stream]
         self._next_stream = (self._next_stream + 1) % self.depth
         side.wait_stream(main)                               # x (and anything producing it) is ready
-        with torch.cuda.stream(side):
-            idx = self._model.sample(x)
+        with torch.cuda.stream(side), torch.no_grad():
+            out = self._model.sample(x)
+            if self._ahead == 'features':
+                out = self._model.cloud_feature_rows(x, out)
             done = torch.cuda.Event()
             done.record(side)
         x.record_stream(side)
-        self._pending.append((x, idx, done))
+        self._pending.append((x, out, done))
 
     def in_flight(self) -> int:
         return len(self._pending)
@@ -46,17 +53,20 @@ class PipelinedForward:
         not yet being sampled; as many as fit the pipeline depth are started before this batch's dense
         stages are enqueued, so they run beside them."""
         main = torch.cuda.current_stream()
-        idx = None
+        ready = None
         if self._pending and self._pending[0][0] is x:
-            _, idx, done = self._pending.popleft()
+            _, ready, done = self._pending.popleft()
             main.wait_event(done)
-            idx.record_stream(main)
+            ready.record_stream(main)
         for nxt in upcoming:
             if len(self._pending) >= self.depth:
                 break
             self.prefetch(nxt)
         with torch.no_grad():
-            f_rows = self._model.cloud_feature_rows(x, idx)
+            if ready is not None and self._ahead == 'features':
+                f_rows = ready
+            else:
+                f_rows = self._model.cloud_feature_rows(x, ready)
             return self._model.merge_rows(f_rows, x.shape[0] // 2)
 
     def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
