@@ -318,7 +318,9 @@ template <int WGS, int P, int G>
 __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int m,
                                                          const float *__restrict__ pts,
                                                          float *__restrict__ temp,
-                                                         int32_t *__restrict__ idx) {
+                                                         int32_t *__restrict__ idx,
+                                                         float4 *__restrict__ group_pts,
+                                                         float *__restrict__ group_box) {
     constexpr int NW = WGS / 64, NP = WGS * P, BINS = 4096, S = P / G;
     static_assert(P % G == 0 && G <= 16 && NW <= 16 && BINS % WGS == 0, "layout");
     typedef typename VecOf<P>::type vec;
@@ -335,6 +337,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     pts += (size_t)blockIdx.x * n * pstride;
     idx += (size_t)blockIdx.x * m;
     if (temp) temp += (size_t)blockIdx.x * n;
+    if (group_pts) group_pts += (size_t)blockIdx.x * NP;
+    if (group_box) group_box += (size_t)blockIdx.x * NW * G * 8;
 
     // ---- 1. bounding box of the cloud --------------------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -472,12 +476,24 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 any = true;
             }
             vec_set<P>(px, jj, x); vec_set<P>(py, jj, y); vec_set<P>(pz, jj, z); vec_set<P>(td, jj, d);
+            if (group_pts) {                                // regrouped copy for the set-abstraction fast path
+                const bool ok = tkg[i] != 0xFFFFu;
+                group_pts[(size_t)(wave * G + g) * (64 * S) + i * 64 + lane] =
+                    make_float4(ok ? x : 3.0e38f, ok ? y : 3.0e38f, ok ? z : 3.0e38f,
+                                __uint_as_float(ok ? fps_tk1024_inv(tkg[i]) : 0xFFFFFFFFu));
+            }
         }
+        float box[6];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float l = fps_shfl_min(blo[a]), h = fps_shfl_max(bhi[a]);
             if (lane == g) { glo[a] = l; ghi[a] = h; }
+            box[a] = l; box[3 + a] = h;
         }
+        if (group_box && lane < 8)
+            group_box[(size_t)(wave * G + g) * 8 + lane] =
+                lane == 0 ? box[0] : lane == 1 ? box[1] : lane == 2 ? box[2] : lane == 3 ? box[3]
+                : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         gbest[g] = any ? 0.f : -1.0f;
         gjj[g] = g * S;
         if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
@@ -664,28 +680,37 @@ void launch_reg(int b, int n, int pstride, int m, const float *pts, float *temp,
 }
 
 template <int WGS, int P, int G>
-void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, hipStream_t s) {
+void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, float4 *group_pts,
+                   float *group_box, hipStream_t s) {
     constexpr int NP = WGS * P;
     const size_t lds = ((size_t)4096 + (size_t)NP + (size_t)(m > NP ? m : NP)) * sizeof(uint32_t);
-    hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx);
+    hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+                       group_pts, group_box);
+}
+
+// Spatial groups the pruned kernel forms (and can export): 16 waves x G groups of 64 * (P / G) points.
+bool fps_group_layout(int n, int *n_groups, int *group_size) {
+    if (n <= 1024 || n > 16384) return false;
+    const int p = n <= 2048 ? 2 : n <= 4096 ? 4 : n <= 8192 ? 8 : 16;
+    const int g = p >= 4 ? 4 : p;
+    *n_groups = 16 * g;
+    *group_size = 64 * (p / g);
+    return true;
 }
 
 int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx,
-                 hipStream_t s) {
+                 hipStream_t s, float4 *group_pts = nullptr, float *group_box = nullptr) {
     DCLR_REQUIRE(b > 0 && n > 0 && m > 0 && pstride >= 3 && pts && idx);
     if ((size_t)m * sizeof(int32_t) > 64 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
     static const bool plain = getenv("DCLR_FPS_PLAIN") != nullptr;             // A/B switch for measurements
     if (!plain && n > 1024 && n <= 16384) {
-        static const int variant = getenv("DCLR_FPS_VARIANT") ? atoi(getenv("DCLR_FPS_VARIANT")) : 0;
-        if (n <= 2048) launch_pruned<1024, 2, 2>(b, n, pstride, m, pts, temp, idx, s);
-        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, s);
-        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, s);
-        else if (variant == 1) launch_pruned<512, 32, 8>(b, n, pstride, m, pts, temp, idx, s);
-        else if (variant == 2) launch_pruned<512, 32, 16>(b, n, pstride, m, pts, temp, idx, s);
-        else if (variant == 3) launch_pruned<1024, 16, 8>(b, n, pstride, m, pts, temp, idx, s);
-        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, s);
+        if (n <= 2048) launch_pruned<1024, 2, 2>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
+        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
+        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
+        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
         return dclr_launch_status();
     }
+    if (group_pts || group_box) return DCLR_E_UNSUPPORTED;
     if (n <= 1024) launch_reg<1024, 1>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 2048) launch_reg<1024, 2>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 4096) launch_reg<1024, 4>(b, n, pstride, m, pts, temp, idx, s);
@@ -717,4 +742,18 @@ extern "C" int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, 
                                dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3);
     return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream);
+}
+
+extern "C" int dclr_fps_group_layout(int n, int *n_groups, int *group_size) {
+    DCLR_REQUIRE(n_groups && group_size);
+    return fps_group_layout(n, n_groups, group_size) ? DCLR_OK : DCLR_E_UNSUPPORTED;
+}
+
+extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,
+                                       float *group_pts, float *group_box, dclr_stream_t stream) {
+    DCLR_REQUIRE(c >= 3 && group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
+    int ng, gs;
+    if (!fps_group_layout(n, &ng, &gs) || getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
+    return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
+                        group_box);
 }

@@ -17,6 +17,13 @@
 //           sa_drain: the shared MLP with lane = entry and all weights as scalar operands, a
 //           64 x 32 transpose through LDS and a segmented maximum per centroid slot, folded by the
 //           caller into per-(scale, centroid) running maxima held by lane = (row parity, channel).
+//   groups  when the sampling kernel exported its spatial partition (<= 64 compact groups per cloud
+//           with tight boxes), each centroid first tests the group boxes (rounding-safe lower bound
+//           of the distance, as in fps.hip) and scans only the groups its largest ball can reach --
+//           a dozen 64-point slices instead of N/64. Hits then arrive out of index order, which is
+//           irrelevant while a neighbourhood stays within its nsample cap (the max does not care);
+//           a centroid whose count exceeds a cap is left to the exhaustive in-order sweep, which the
+//           workgroup runs only if one of its waves needs it.
 // Slots that would only repeat the first hit are skipped: max() over a multiset equals max() over
 // its support, so the result is identical. A centroid with no hit reproduces the published
 // behaviour (zero-filled index row => every slot is point 0).
@@ -25,9 +32,9 @@
 namespace {
 
 constexpr int SA_WAVES = 4;
-constexpr int SA_CPW = 4;                       // centroids per wave
+constexpr int SA_CPW = 8;                       // centroids per wave
 constexpr int SA_TILE = 512;                    // points per LDS tile
-constexpr int SA_RING = 512;                    // ring capacity (>= 63 + SA_CPW * 64), power of two
+constexpr int SA_RING = 512;                    // ring capacity (>= 63 + 4 * 64 staged between drain checks), power of two
 constexpr int SA_MAX_SCALES = 2;
 constexpr int SA_H1 = 16, SA_H2 = 16, SA_OUT = 32;
 constexpr int SA_OSTRIDE = SA_OUT + 1;          // output row: 32 channels + centroid tag, odd stride
@@ -38,6 +45,9 @@ struct SaParams {
     float radius2_max;
     int nsample[SA_MAX_SCALES];
     const float *mlp[SA_MAX_SCALES];
+    const float4 *group_pts;                    // optional spatial groups from the sampling kernel (or null)
+    const float *group_box;
+    int n_groups, group_size;
 };
 
 template <int C>
@@ -50,12 +60,16 @@ __device__ __forceinline__ float4 sa_load_point(const float *__restrict__ cloud,
     }
 }
 
-// 3-layer shared MLP on one neighbour; weights are wave-uniform (scalar loads).
+constexpr int SA_MLP_FLOATS = SA_H1 * 4 + SA_H1 + SA_H2 * SA_H1 + SA_H2 + SA_OUT * SA_H2 + SA_OUT;   // 896 at c = 4
+
+// 3-layer shared MLP on one neighbour. The weights sit in LDS (staged once per workgroup) and are read
+// with wave-uniform addresses (broadcast): as scalar loads they arrived ~16 at a time through a
+// serial s_load chain and one 64-entry pass took ~34k cycles.
 template <int C>
-__device__ __forceinline__ void sa_mlp(const float *w_global, const float (&in)[4], float (&out)[SA_OUT]) {
-    dclr_const_f32p w1 = dclr_as_const(w_global);
-    dclr_const_f32p b1 = w1 + SA_H1 * C, w2 = b1 + SA_H1, b2 = w2 + SA_H2 * SA_H1;
-    dclr_const_f32p w3 = b2 + SA_H2, b3 = w3 + SA_OUT * SA_H2;
+__device__ __forceinline__ void sa_mlp(const float *w, const float (&in)[4], float (&out)[SA_OUT]) {
+    const float *w1 = w;
+    const float *b1 = w1 + SA_H1 * C, *w2 = b1 + SA_H1, *b2 = w2 + SA_H2 * SA_H1;
+    const float *w3 = b2 + SA_H2, *b3 = w3 + SA_OUT * SA_H2;
     float h1[SA_H1], h2[SA_H2];
 #pragma unroll
     for (int o = 0; o < SA_H1; ++o) {
@@ -84,20 +98,20 @@ __device__ __forceinline__ void sa_mlp(const float *w_global, const float (&in)[
 // address it; both template instances of the kernel use the same layout.
 __shared__ float4 sa_tile[2][SA_TILE];
 __shared__ uint32_t sa_ring[SA_WAVES][SA_MAX_SCALES][SA_RING];
-__shared__ float sa_obuf[SA_WAVES][64 * SA_OSTRIDE];
+__shared__ float sa_obuf[SA_WAVES][32 * SA_OSTRIDE];   // half a drain at a time: keeps 3 workgroups per CU
 __shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
 
-struct SaMax4 {
-    float v[SA_CPW];
-};
+// running maxima per (wave, scale, centroid slot, channel): non-negative floats, compared as u32
+__shared__ uint32_t sa_acc[SA_WAVES][SA_MAX_SCALES][SA_CPW][SA_OUT];
+__shared__ int sa_tot[SA_WAVES][SA_CPW][SA_MAX_SCALES];
+__shared__ __attribute__((aligned(16))) float sa_w[SA_MAX_SCALES][SA_MLP_FLOATS];       // true neighbour counts of centroids done on the fast path
 
-// One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`, lane = entry. Returns,
-// for lane = (row parity, channel), the maxima of this pass per centroid slot; the caller folds them
-// into its running maxima. Kept out of line on purpose: inlined into the sweep loop its ~100 scalar
+// One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`, lane = entry; the results
+// are folded into sa_acc. Kept out of line on purpose: inlined into the sweep loop its ~100 scalar
 // weight registers push the loop-carried scalars (centroids, counters) into spill lanes.
 template <int C>
-__device__ __noinline__ SaMax4 sa_drain(const float *cloud, const float *mlp, int wave, int s, int head, int take) {
-    cloud = dclr_uniform(cloud); mlp = dclr_uniform(mlp);
+__device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int head, int take) {
+    cloud = dclr_uniform(cloud);
     wave = dclr_uniform(wave); s = dclr_uniform(s); head = dclr_uniform(head); take = dclr_uniform(take);
     const int lane = dclr_lane();
     const bool valid = lane < take;
@@ -106,24 +120,54 @@ __device__ __noinline__ SaMax4 sa_drain(const float *cloud, const float *mlp, in
     const float4 p = sa_load_point<C>(cloud, k);
     float in[4] = {p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w};
     float h[SA_OUT];
-    sa_mlp<C>(mlp, in, h);
-    float *orow = &sa_obuf[wave][lane * SA_OSTRIDE];
-#pragma unroll
-    for (int o = 0; o < SA_OUT; ++o) orow[o] = h[o];
-    orow[SA_OUT] = __int_as_float(c);
-    // rows of one wave only: the wave's own LDS writes are ordered before its reads
-    SaMax4 out;
-#pragma unroll
-    for (int cc = 0; cc < SA_CPW; ++cc) out.v[cc] = 0.f;
+    sa_mlp<C>(&sa_w[s][0], in, h);
+    // transpose through LDS in two halves of 32 entries (rows of one wave only: the wave's own LDS
+    // writes are ordered before its reads). Lane = (row parity, channel) walks the rows; entries of a
+    // centroid mostly form runs, so the running maximum is committed (LDS atomic max) only when the
+    // centroid changes.
     const int ch = lane & 31;
-    for (int r = lane >> 5; r < take; r += 2) {
-        const float v = sa_obuf[wave][r * SA_OSTRIDE + ch];
-        const int rc = __float_as_int(sa_obuf[wave][r * SA_OSTRIDE + SA_OUT]);
+    uint32_t *acc = &sa_acc[wave][s][0][ch];
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int rows = take - 32 * half < 32 ? take - 32 * half : 32;     // wave-uniform
+        if (rows <= 0) break;
+        if ((lane >> 5) == half) {
+            float *orow = &sa_obuf[wave][(lane & 31) * SA_OSTRIDE];
 #pragma unroll
-        for (int cc = 0; cc < SA_CPW; ++cc) out.v[cc] = rc == cc ? fmaxf(out.v[cc], v) : out.v[cc];
+            for (int o = 0; o < SA_OUT; ++o) orow[o] = h[o];
+            orow[SA_OUT] = __int_as_float(c);
+        }
+        int cur = -1;
+        float m = 0.f;
+        for (int r = lane >> 5; r < rows; r += 2) {
+            const float v = sa_obuf[wave][r * SA_OSTRIDE + ch];
+            const int rc = __float_as_int(sa_obuf[wave][r * SA_OSTRIDE + SA_OUT]);
+            if (rc != cur) {
+                if (cur >= 0) atomicMax(acc + cur * SA_OUT, __float_as_uint(m));
+                cur = rc;
+                m = 0.f;
+            }
+            m = fmaxf(m, v);
+        }
+        if (cur >= 0) atomicMax(acc + cur * SA_OUT, __float_as_uint(m));
     }
-    return out;
 }
+
+// Rounded lower bound of dclr_sqdist(c, p) over all p in the box (same operation order; rounding is monotone).
+__device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz, float hx, float hy, float hz,
+                                                    float cx, float cy, float cz) {
+    const float dx = fmaxf(fmaxf(lx - cx, cx - hx), 0.f);
+    const float dy = fmaxf(fmaxf(ly - cy, cy - hy), 0.f);
+    const float dz = fmaxf(fmaxf(lz - cz, cz - hz), 0.f);
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+#ifdef SA_DEBUG
+__device__ unsigned long long sa_dbg[8];       // cycles: [0] total, [1] fast path incl. drains, [2] drains, [3] #drains, [4] sweep, [5] #waves
+#define SA_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#endif
 
 template <int C>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
@@ -156,82 +200,198 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
     }
 
     int qhead[SA_MAX_SCALES] = {0, 0}, qn[SA_MAX_SCALES] = {0, 0};
-    float mx[SA_MAX_SCALES][SA_CPW];                                    // lane = (row parity, channel)
-#pragma unroll
-    for (int s = 0; s < SA_MAX_SCALES; ++s)
-#pragma unroll
-        for (int c = 0; c < SA_CPW; ++c) mx[s][c] = 0.f;                // post-ReLU values are >= 0
+    for (int i = lane; i < SA_MAX_SCALES * SA_CPW * SA_OUT; i += 64)
+        (&sa_acc[wave][0][0][0])[i] = 0u;                              // post-ReLU values are >= 0
+    {
+        const int mlp_floats = SA_H1 * C + SA_H1 + SA_H2 * SA_H1 + SA_H2 + SA_OUT * SA_H2 + SA_OUT;
+        for (int s = 0; s < prm.n_scales; ++s)
+            for (int i = tid; i < mlp_floats; i += SA_WAVES * 64) sa_w[s][i] = prm.mlp[s][i];
+    }
+    __syncthreads();
 
-    const int n_tiles = (prm.n + SA_TILE - 1) / SA_TILE;
-    constexpr int PER_THREAD = SA_TILE / (SA_WAVES * 64);               // points staged per thread
-    float4 stage[PER_THREAD];
-    auto fetch = [&](int t) {
-#pragma unroll
-        for (int u = 0; u < PER_THREAD; ++u) {
-            const int k = t * SA_TILE + u * (SA_WAVES * 64) + tid;
-            stage[u] = k < prm.n ? sa_load_point<C>(cloud, k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < PER_THREAD; ++u) sa_tile[buf][u * (SA_WAVES * 64) + tid] = stage[u];
-    };
-    fetch(0);
-    stash(0);
-
+#ifdef SA_DEBUG
+    unsigned long long t_begin, t_fast = 0, t_drain = 0, n_drain = 0, t_sweep = 0;
+    SA_STAMP(t_begin);
+#endif
     auto drain_all = [&](bool final_pass) {
 #pragma unroll
         for (int s = 0; s < SA_MAX_SCALES; ++s) {
             if (s >= prm.n_scales) break;
             while (qn[s] >= 64 || (final_pass && qn[s] > 0)) {
                 const int take = qn[s] < 64 ? qn[s] : 64;
-                const SaMax4 r = sa_drain<C>(cloud, prm.mlp[s], wave, s, qhead[s], take);
-#pragma unroll
-                for (int c = 0; c < SA_CPW; ++c) mx[s][c] = fmaxf(mx[s][c], r.v[c]);
+#ifdef SA_DEBUG
+                unsigned long long d0, d1;
+                SA_STAMP(d0);
+#endif
+                sa_drain<C>(cloud, wave, s, qhead[s], take);
+#ifdef SA_DEBUG
+                SA_STAMP(d1);
+                t_drain += d1 - d0; n_drain += 1;
+#endif
                 qhead[s] += take;
                 qn[s] -= take;
             }
         }
     };
 
-    for (int t = 0; t < n_tiles; ++t) {
-        __syncthreads();                                   // tile t is in sa_tile[t & 1]
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) fetch(t + 1);
-        for (int it = 0; it < SA_TILE / 64; ++it) {
-            const int k = t * SA_TILE + it * 64 + lane;
-            const float4 p = sa_tile[buf][it * 64 + lane];
-            const bool inb = k < prm.n;
-            float d2c[SA_CPW];
+    // ---- fast path over the sampling kernel's spatial groups ---------------------------------------
+    // Runtime loop over the wave's centroids (coordinates and counts through LDS) to keep one small
+    // copy of the code; `done` bit c = centroid slot c is finished, its true counts are in sa_tot.
+    uint32_t done = 0;
+    bool need_sweep = prm.group_pts == nullptr;
+    if (prm.group_pts != nullptr) {
+        const float4 *gp = prm.group_pts + bi * (size_t)prm.n_groups * prm.group_size;
+        const float *gb = prm.group_box + (bi * prm.n_groups + (lane < prm.n_groups ? lane : 0)) * 8;
+        const bool have = lane < prm.n_groups;             // n_groups <= 64: lane g owns group g's box
+        const float blx = have ? gb[0] : 3.0e38f, bly = have ? gb[1] : 3.0e38f, blz = have ? gb[2] : 3.0e38f;
+        const float bhx = have ? gb[3] : -3.0e38f, bhy = have ? gb[4] : -3.0e38f, bhz = have ? gb[5] : -3.0e38f;
+        const int slices = prm.group_size / 64;
+#pragma unroll 1
+        for (int c = 0; c < n_live; ++c) {
+            const float cx = sa_cxyz[wave][c][0], cy = sa_cxyz[wave][c][1], cz = sa_cxyz[wave][c][2];
+            const float lbv = sa_box_lower_bound(blx, bly, blz, bhx, bhy, bhz, cx, cy, cz);
+            const uint64_t gmask = __ballot(have && lbv < prm.radius2_max);
+            // pass 1: count the neighbours of both scales
+            int n1[SA_MAX_SCALES] = {0, 0};
+            // two candidate groups (<= 8 slices of 64 points) per step, all loads issued before the first
+            // use: one slice at a time the scan is a chain of ~250 dependent L2 round trips per wave
+            auto load_pair = [&](uint64_t &m, float4 (&q)[8], int &nq) {
+                const int ga = __builtin_ctzll(m);
+                m &= m - 1;
+                const bool two = m != 0;
+                const int gbb = two ? __builtin_ctzll(m) : ga;
+                if (two) m &= m - 1;
+                const float4 *pa = gp + (size_t)ga * prm.group_size + lane;
+                const float4 *pb = gp + (size_t)gbb * prm.group_size + lane;
 #pragma unroll
-            for (int c = 0; c < SA_CPW; ++c) d2c[c] = dclr_sqdist(ccx[c], ccy[c], ccz[c], p.x, p.y, p.z);
-            // common case: no lane is inside the largest ball of any of the wave's centroids
-            const float dmin = fminf(fminf(d2c[0], d2c[1]), fminf(d2c[2], d2c[3]));
-            if (__ballot(inb && dmin < prm.radius2_max) == 0) continue;
+                for (int it = 0; it < 4; ++it) {
+                    const int ic = it < slices ? it : slices - 1;           // clamped: loads stay unconditional
+                    q[it] = pa[ic * 64];
+                    q[4 + it] = pb[ic * 64];
+                }
+                nq = two ? 8 : 4;
+            };
+            for (uint64_t m = gmask; m != 0;) {
+                float4 q[8];
+                int nq;
+                load_pair(m, q, nq);
 #pragma unroll
-            for (int c = 0; c < SA_CPW; ++c) {
-                const float d2 = d2c[c];
+                for (int u = 0; u < 8; ++u) {
+                    const bool valid = (u & 3) < slices && u < nq && __float_as_uint(q[u].w) != 0xFFFFFFFFu;
+                    const float d2 = dclr_sqdist(cx, cy, cz, q[u].x, q[u].y, q[u].z);
 #pragma unroll
-                for (int s = 0; s < SA_MAX_SCALES; ++s) {
-                    if (s >= prm.n_scales) break;
-                    const bool hit = inb && d2 < prm.radius2[s];
-                    const uint64_t mask = __ballot(hit);
-                    if (__builtin_expect(mask != 0 && cnt[c][s] < prm.nsample[s], 0)) {   // wave-uniform, rare
-                        const int room = prm.nsample[s] - cnt[c][s];
-                        const int pre = (int)dclr_lanemask_lt_popc(mask);
-                        int nt = __builtin_popcountll(mask);
-                        nt = nt < room ? nt : room;
-                        if (hit && pre < room)
-                            sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = ((uint32_t)c << 16) | (uint32_t)k;
-                        qn[s] += nt;
-                        cnt[c][s] += nt;
-                    }
+                    for (int s = 0; s < SA_MAX_SCALES; ++s)
+                        if (s < prm.n_scales) n1[s] += __builtin_popcountll(__ballot(valid && d2 < prm.radius2[s]));
                 }
             }
-            if (__builtin_expect(qn[0] >= 64 || qn[1] >= 64, 0)) drain_all(false);
+            if (n1[0] > prm.nsample[0] || (prm.n_scales > 1 && n1[1] > prm.nsample[1])) {
+                need_sweep = true;                         // cap reached: index order matters -> in-order sweep
+                continue;
+            }
+            // pass 2: stage the neighbours (any order) for the MLP
+            for (uint64_t m = gmask; m != 0;) {
+                float4 q[8];
+                int nq;
+                load_pair(m, q, nq);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool valid = (u & 3) < slices && u < nq && __float_as_uint(q[u].w) != 0xFFFFFFFFu;
+                    const float d2 = dclr_sqdist(cx, cy, cz, q[u].x, q[u].y, q[u].z);
+#pragma unroll
+                    for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                        if (s >= prm.n_scales) break;
+                        const bool hit = valid && d2 < prm.radius2[s];
+                        const uint64_t mask = __ballot(hit);
+                        if (mask != 0) {
+                            const int pre = (int)dclr_lanemask_lt_popc(mask);
+                            if (hit)
+                                sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] =
+                                    ((uint32_t)c << 16) | (__float_as_uint(q[u].w) & 0xFFFFu);
+                            qn[s] += __builtin_popcountll(mask);
+                        }
+                    }
+                    if ((u & 3) == 3 && (qn[0] >= 64 || qn[1] >= 64)) drain_all(false);   // <= 256 staged per check
+                }
+            }
+            done |= 1u << c;
+            if (lane == 0) { sa_tot[wave][c][0] = n1[0]; sa_tot[wave][c][1] = n1[1]; }
         }
-        if (t + 1 < n_tiles) stash(buf ^ 1);
     }
+#pragma unroll
+    for (int c = 0; c < SA_CPW; ++c)
+        if ((done >> c) & 1u) { cnt[c][0] = prm.nsample[0]; cnt[c][1] = prm.nsample[1]; }   // closed for the sweep
+
+#ifdef SA_DEBUG
+    { unsigned long long t1; SA_STAMP(t1); t_fast = t1 - t_begin; }
+#endif
+    // ---- exhaustive in-order sweep: only if some wave of the workgroup still has open centroids -----
+    if (__syncthreads_or(need_sweep ? 1 : 0)) {
+#ifdef SA_DEBUG
+        unsigned long long w0; SA_STAMP(w0);
+#endif
+        const int n_tiles = (prm.n + SA_TILE - 1) / SA_TILE;
+        constexpr int PER_THREAD = SA_TILE / (SA_WAVES * 64);           // points staged per thread
+        float4 stage[PER_THREAD];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int u = 0; u < PER_THREAD; ++u) {
+                const int k = t * SA_TILE + u * (SA_WAVES * 64) + tid;
+                stage[u] = k < prm.n ? sa_load_point<C>(cloud, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto stash = [&](int buf) {
+#pragma unroll
+            for (int u = 0; u < PER_THREAD; ++u) sa_tile[buf][u * (SA_WAVES * 64) + tid] = stage[u];
+        };
+        fetch(0);
+        stash(0);
+        for (int t = 0; t < n_tiles; ++t) {
+            __syncthreads();                               // tile t is in sa_tile[t & 1]
+            const int buf = t & 1;
+            if (t + 1 < n_tiles) fetch(t + 1);
+            for (int it = 0; it < SA_TILE / 64; ++it) {
+                const int k = t * SA_TILE + it * 64 + lane;
+                const float4 p = sa_tile[buf][it * 64 + lane];
+                const bool inb = k < prm.n;
+                float d2c[SA_CPW];
+#pragma unroll
+                for (int c = 0; c < SA_CPW; ++c) d2c[c] = dclr_sqdist(ccx[c], ccy[c], ccz[c], p.x, p.y, p.z);
+                // common case: no lane is inside the largest ball of any of the wave's centroids
+                float dmin = d2c[0];
+#pragma unroll
+                for (int c = 1; c < SA_CPW; ++c) dmin = fminf(dmin, d2c[c]);
+                if (__ballot(inb && dmin < prm.radius2_max) == 0) continue;
+#pragma unroll
+                for (int c = 0; c < SA_CPW; ++c) {
+                    const float d2 = d2c[c];
+#pragma unroll
+                    for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                        if (s >= prm.n_scales) break;
+                        const bool hit = inb && d2 < prm.radius2[s];
+                        const uint64_t mask = __ballot(hit);
+                        if (__builtin_expect(mask != 0 && cnt[c][s] < prm.nsample[s], 0)) {   // wave-uniform, rare
+                            const int room = prm.nsample[s] - cnt[c][s];
+                            const int pre = (int)dclr_lanemask_lt_popc(mask);
+                            int nt = __builtin_popcountll(mask);
+                            nt = nt < room ? nt : room;
+                            if (hit && pre < room)
+                                sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = ((uint32_t)c << 16) | (uint32_t)k;
+                            qn[s] += nt;
+                            cnt[c][s] += nt;
+                        }
+                    }
+                    if ((c & 3) == 3 && __builtin_expect(qn[0] >= 64 || qn[1] >= 64, 0)) drain_all(false);
+                }
+            }
+            if (t + 1 < n_tiles) stash(buf ^ 1);
+        }
+#ifdef SA_DEBUG
+        { unsigned long long w1; SA_STAMP(w1); t_sweep = w1 - w0; }
+#endif
+    }
+#pragma unroll
+    for (int c = 0; c < SA_CPW; ++c)
+        if ((done >> c) & 1u) { cnt[c][0] = sa_tot[wave][c][0]; cnt[c][1] = sa_tot[wave][c][1]; }
 
     // published behaviour for a centroid without any hit: its (zero-filled) index row means point 0
 #pragma unroll
@@ -250,17 +410,19 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
     for (int c = 0; c < SA_CPW; ++c) {
         if (c >= n_live) break;
         float *orow = out_rows + (bi * prm.npoint + j0 + c) * DCLR_F_STRIDE;
-        float v = 0.f;                                                  // columns of an absent scale stay zero
-#pragma unroll
-        for (int s = 0; s < SA_MAX_SCALES; ++s) {
-            const float m = fmaxf(mx[s][c], __shfl_xor(mx[s][c], 32));   // rows were split over the lane halves
-            if (s < prm.n_scales && (lane >> 5) == s) v = m;
-        }
-        orow[lane] = v;                                                 // lane = s * 32 + channel
+        // lane = s * 32 + channel; columns of an absent scale stay zero
+        orow[lane] = (lane >> 5) < prm.n_scales ? __uint_as_float(sa_acc[wave][lane >> 5][c][lane & 31]) : 0.f;
         if (lane < 4) orow[64 + lane] = lane == 0 ? ccx[c] : (lane == 1 ? ccy[c] : (lane == 2 ? ccz[c] : 0.f));
         if (counts && lane < prm.n_scales)
             counts[(bi * prm.npoint + j0 + c) * prm.n_scales + lane] = lane == 0 ? cnt[c][0] : cnt[c][1];
     }
+#ifdef SA_DEBUG
+    if (lane == 0) {
+        unsigned long long t_end; SA_STAMP(t_end);
+        atomicAdd(&sa_dbg[0], t_end - t_begin); atomicAdd(&sa_dbg[1], t_fast); atomicAdd(&sa_dbg[2], t_drain);
+        atomicAdd(&sa_dbg[3], n_drain); atomicAdd(&sa_dbg[4], t_sweep); atomicAdd(&sa_dbg[5], 1ull);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void rows_to_channels_kernel(int npoint, int nfeat, int xyz_col, int stride,
@@ -293,7 +455,8 @@ __global__ __launch_bounds__(256) void channels_to_rows_kernel(int npoint, int n
 extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *clouds,
                                  const int32_t *fps_idx, int n_scales, const float *radii_host,
                                  const int *nsamples_host, const float *const *mlp_host_ptrs,
-                                 float *out_rows, int32_t *counts, dclr_stream_t stream) {
+                                 float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
+                                 dclr_stream_t stream) {
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
@@ -306,6 +469,12 @@ extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *c
         prm.radius2_max = s == 0 || prm.radius2[s] > prm.radius2_max ? prm.radius2[s] : prm.radius2_max;
         prm.nsample[s] = nsamples_host[s];
         prm.mlp[s] = mlp_host_ptrs[s];
+    }
+    if (group_pts || group_box) {
+        DCLR_REQUIRE(group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
+        if (dclr_fps_group_layout(n, &prm.n_groups, &prm.group_size) != DCLR_OK || prm.n_groups > 64) return DCLR_E_INVALID;
+        prm.group_pts = reinterpret_cast<const float4 *>(group_pts);
+        prm.group_box = group_box;
     }
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);

@@ -25,7 +25,9 @@ SIGNATURES = {
     'dclr_group_points': [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     'dclr_knn': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_fps_clouds': [_i, _i, _i, _i, _p, _p, _p],
-    'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    'dclr_fps_group_layout': [_i, _p, _p],
+    'dclr_fps_clouds_grouped': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
+    'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_channels_to_rows': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],

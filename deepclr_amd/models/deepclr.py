@@ -75,12 +75,12 @@ class SetAbstraction(DeepCLRModule):
     def output_dim(self) -> int:
         return 3 + self._output_feat_dim
 
-    def sample(self, clouds: torch.Tensor) -> torch.Tensor:
+    def sample(self, clouds: torch.Tensor):
         return self._sa0.sample(clouds)
 
-    def forward_rows(self, clouds: torch.Tensor, fps_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
         """(2B, N, C) point-major clouds -> rows F."""
-        return self._sa0.forward_rows(clouds, fps_idx)
+        return self._sa0.forward_rows(clouds, sample)
 
     def forward(self, clouds: torch.Tensor, *_args: Any) -> torch.Tensor:
         """(2B, C, N) channel-major clouds -> (2B, 3 + feat, npoint), as the reference module."""
@@ -319,13 +319,13 @@ class DeepCLR(BaseModel):
         return self._cloud_layers[0].npoint
 
     # -- row-level pipeline (what bench.py and the sharded runner drive) ---------------------------
-    def sample(self, x: torch.Tensor) -> torch.Tensor:
-        """(2B, N, C) -> (2B, npoint) int32 furthest-point sample indices."""
+    def sample(self, x: torch.Tensor):
+        """(2B, N, C) -> furthest-point sample (indices (2B, npoint) int32 + the kernel's spatial groups)."""
         return self._cloud_layers[0].sample(x)
 
-    def cloud_feature_rows(self, x: torch.Tensor, fps_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """(2B, N, C) -> rows F ((2B)*npoint, 68); fps_idx: precomputed sample(x), else computed here."""
-        return self._cloud_layers[0].forward_rows(x, fps_idx)
+    def cloud_feature_rows(self, x: torch.Tensor, sample=None) -> torch.Tensor:
+        """(2B, N, C) -> rows F ((2B)*npoint, 68); sample: precomputed self.sample(x), else computed here."""
+        return self._cloud_layers[0].forward_rows(x, sample)
 
     def merge_rows(self, f_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)

@@ -120,6 +120,30 @@ def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
     return idx
 
 
+def fps_group_layout(n: int):
+    """(n_groups, group_size) of the spatial partition the sampling kernel can export, or None."""
+    ng, gs = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib.load().dclr_fps_group_layout(n, ctypes.addressof(ng), ctypes.addressof(gs))
+    return (ng.value, gs.value) if rc == 0 else None
+
+
+def fps_clouds_grouped(clouds: torch.Tensor, npoint: int):
+    """Sampling plus the kernel's spatial groups: (idx, group_pts, group_box); the last two are None when
+    the cloud size has no grouped kernel (then set abstraction sweeps exhaustively)."""
+    clouds = lib.dev_f32(clouds, 'clouds')
+    b, n, c = clouds.shape
+    layout = fps_group_layout(n)
+    if layout is None:
+        return fps_clouds(clouds, npoint), None, None
+    ng, gs = layout
+    idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
+    gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
+    gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
+    _call('dclr_fps_clouds_grouped', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
+          gbox.data_ptr(), lib.stream_ptr())
+    return idx, gpts, gbox
+
+
 def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
     """[W1 b1 W2 b2 W3 b3] flat f32 buffer for dclr_sa_msg_fused (1x1 conv weights (out,in,1,1))."""
     parts = []
@@ -129,8 +153,9 @@ def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor])
 
 
 def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[float], nsamples: Sequence[int],
-                 mlps: List[torch.Tensor], want_counts: bool = False):
-    """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)]."""
+                 mlps: List[torch.Tensor], want_counts: bool = False, groups=None):
+    """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)].
+    groups: (group_pts, group_box) from fps_clouds_grouped for the same clouds, or None."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
     npoint = fps_idx.shape[1]
@@ -143,7 +168,8 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     _call('dclr_sa_msg_fused', 'sa_msg_fused', b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
                                            ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
                                            ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
-                                           lib.stream_ptr())
+          None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
+          lib.stream_ptr())
     return (out, counts) if want_counts else out
 
 

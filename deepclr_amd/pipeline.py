@@ -57,7 +57,9 @@ class PipelinedForward:
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
             main.wait_event(done)
-            ready.record_stream(main)
+            for t in (ready if isinstance(ready, tuple) else (ready,)):
+                if t is not None:
+                    t.record_stream(main)
         for nxt in upcoming:
             if len(self._pending) >= self.depth:
                 break

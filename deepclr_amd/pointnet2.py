@@ -81,18 +81,21 @@ class PointnetSAModuleMSG(nn.Module):
                     for stack in self.mlps]
         return self._cache.get(list(self.parameters()), build)
 
-    def sample(self, clouds: torch.Tensor) -> torch.Tensor:
-        """Furthest point sampling only: clouds (B, N, C) -> (B, npoint) int32 (the serial stage; the
-        pipelined runner issues it one batch ahead on a side stream)."""
+    def sample(self, clouds: torch.Tensor):
+        """Furthest point sampling only (the serial stage; the pipelined runner issues it batches ahead
+        on side streams): clouds (B, N, C) -> (idx (B, npoint) int32, group_pts, group_box); the group
+        tensors are the sampling kernel's spatial partition, or None when it has none for this N."""
         if clouds.shape[2] != 3 + self._in_feat:
             raise RuntimeError("expected {} columns per point, got {}".format(3 + self._in_feat, clouds.shape[2]))
-        return ops.fps_clouds(clouds, self.npoint)
+        return ops.fps_clouds_grouped(clouds, self.npoint)
 
-    def forward_rows(self, clouds: torch.Tensor, fps_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68)."""
-        if fps_idx is None:
-            fps_idx = self.sample(clouds)
-        return ops.sa_msg_fused(clouds, fps_idx, self.radii, self.nsamples, self.packed_mlps())
+    def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
+        """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68); sample = self.sample(clouds)."""
+        if sample is None:
+            sample = self.sample(clouds)
+        idx, gpts, gbox = sample
+        groups = None if gpts is None else (gpts, gbox)
+        return ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, self.packed_mlps(), groups=groups)
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
                 new_xyz: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

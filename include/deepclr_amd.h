@@ -95,6 +95,16 @@ int dclr_knn(int b, int nx, int ny, int k, const float *x, const float *y, int64
 int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *idx,
                     dclr_stream_t stream);
 
+/* The same sampling, additionally exporting the spatial partition the kernel builds for its own
+ * pruning: every cloud is split into n_groups compact groups of group_size points
+ * (dclr_fps_group_layout; available for 1024 < n <= 16384, otherwise DCLR_E_UNSUPPORTED).
+ * group_pts (b, n_groups*group_size, 4) f32: x y z and the point index as raw u32 bits (0xFFFFFFFF =
+ * padding slot, coordinates 3e38); group_box (b, n_groups, 8) f32: min xyz, max xyz, 0, 0.
+ * dclr_sa_msg_fused uses them to skip the exhaustive ball-query sweep. */
+int dclr_fps_group_layout(int n, int *n_groups, int *group_size);
+int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,
+                            float *group_pts, float *group_box, dclr_stream_t stream);
+
 /* Set abstraction, multi-scale grouping, fused (reference: SetAbstraction.forward,
  * /root/reference/deepclr/models/deepclr.py:88-94, -> PointnetSAModuleMSG with use_xyz=True, bn=False):
  * per sampled centroid and scale: ball query -> [xyz - centroid, features] -> 1x1-conv MLP
@@ -103,11 +113,12 @@ int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *id
  * clouds (b,n,c), c in {3,4}; fps_idx (b,npoint); n_scales in {1,2}; radii_host/nsamples_host are
  * HOST arrays read at call time; mlp[s] is a device array [W1(16,c) b1(16) W2(16,16) b2(16) W3(32,16) b3(32)];
  * out rows F (b*npoint, 68), scale s at columns 32*s..; counts (b,npoint,n_scales) i32 or NULL
- * receives min(hits, nsample) per centroid (diagnostics / parity tests). */
+ * receives min(hits, nsample) per centroid (diagnostics / parity tests). group_pts / group_box: the
+ * optional outputs of dclr_fps_clouds_grouped for the same clouds (both NULL: exhaustive sweep). */
 int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx,
                       int n_scales, const float *radii_host, const int *nsamples_host,
                       const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
-                      dclr_stream_t stream);
+                      const float *group_pts, const float *group_box, dclr_stream_t stream);
 
 /* Layout conversion between rows F/E and the reference's channel-major tensors:
  * channels (b, 3 + nfeat, npoint) with xyz in channels 0..2  <->  rows (b*npoint, stride) with the

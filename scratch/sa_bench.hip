@@ -1,0 +1,46 @@
+// Diagnostic harness for the set-abstraction kernel (not part of the product): hipcc -DSA_DEBUG ...
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../deepclr_amd/csrc/fps.hip"
+#include "../deepclr_amd/csrc/sa.hip"
+
+int main(int argc, char **argv) {
+    const int b = 16, n = 16384, m = 1024, c = 4;
+    const bool use_groups = argc < 2 || atoi(argv[1]) != 0;
+    std::mt19937 rng(1);
+    std::normal_distribution<float> g(0.f, 1.f);
+    std::uniform_real_distribution<float> u(-0.3f, 0.3f);
+    std::vector<float> h((size_t)b * n * c);
+    for (size_t i = 0; i < (size_t)b * n; ++i) {
+        h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
+    }
+    std::vector<float> w(2 * 896);
+    for (auto &v : w) v = u(rng);
+    float *d, *gp, *gb, *rows, *wd; int32_t *idx;
+    hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4); hipMalloc(&gp, (size_t)b * 16384 * 16);
+    hipMalloc(&gb, (size_t)b * 64 * 32); hipMalloc(&rows, (size_t)b * m * 68 * 4); hipMalloc(&wd, w.size() * 4);
+    hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(wd, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+    int rc = dclr_fps_clouds_grouped(b, n, c, m, d, idx, gp, gb, nullptr);
+    hipDeviceSynchronize();
+    const float radii[2] = {0.5f, 1.0f}; const int ns[2] = {512, 1024};
+    const float *mlps[2] = {wd, wd + 896};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        unsigned long long zero[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg), zero, sizeof(zero));
+        hipEventRecord(e0);
+        int rc2 = dclr_sa_msg_fused(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
+                                    use_groups ? gb : nullptr, nullptr);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long dbg[8];
+        hipMemcpyFromSymbol(dbg, HIP_SYMBOL(sa_dbg), sizeof(dbg));
+        const double nw = dbg[5] ? (double)dbg[5] : 1;
+        printf("rc=%d/%d groups=%d  %.1f us | per wave (cycles): total %.0f  fast-path(incl drains) %.0f  drains %.0f (%.2f drains)  sweep %.0f | waves %.0f\n",
+               rc, rc2, (int)use_groups, ms * 1e3, dbg[0] / nw, dbg[1] / nw, dbg[2] / nw, dbg[3] / nw, dbg[4] / nw, nw);
+    }
+    return 0;
+}

@@ -145,8 +145,19 @@ def test_fused_set_abstraction_dense_neighbourhoods(c, n, npoint, radii, nsample
         new_xyz, feat = sam(xyz.to(DEV), None if feats is None else feats.to(DEV))
     assert torch.equal(new_xyz.cpu(), new_xyz_o)
     _close(feat, feat_o)
-    fps = ops.fps_clouds(x.to(DEV), npoint)
-    _, counts = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True)
+    fps, gpts, gbox = ops.fps_clouds_grouped(x.to(DEV), npoint)
+    assert torch.equal(fps, ops.fps_clouds(x.to(DEV), npoint)) and (gpts is not None) == (n > 1024)
+    rows_a, counts = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True)
+    if gpts is not None:                              # spatial-group fast path == exhaustive sweep, bit for bit
+        rows_b, counts_b = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(),
+                                            want_counts=True, groups=(gpts, gbox))
+        assert torch.equal(counts, counts_b)
+        assert torch.equal(rows_a, rows_b)
+        k = gpts[..., 3].contiguous().view(torch.int32)   # the groups are a permutation of the cloud
+        for b_ in range(x.shape[0]):
+            kk = k[b_][k[b_] >= 0].long()
+            assert sorted(kk.tolist()) == list(range(n))
+            assert torch.equal(gpts[b_][k[b_] >= 0][:, :3], x.to(DEV)[b_, kk, :3])
     for s, (r, ns) in enumerate(zip(radii, nsamples)):
         bq = oracle.ball_query(r, ns, xyz, new_xyz_o)
         hits = 1 + (bq[:, :, 1:] != bq[:, :, :1]).sum(-1)
