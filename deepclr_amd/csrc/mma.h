@@ -56,32 +56,43 @@ __device__ __forceinline__ void dclr_mma_group(dclr_f32x16 (&acc)[MT][NT], const
 // before the MFMAs of group g are issued (a fragment load is an L2 round trip; asking for it right
 // before use leaves the matrix pipe idle whenever the co-resident waves stall the same way).
 template <int MT, int NT>
+__device__ __forceinline__ void dclr_mma_step(dclr_f32x16 (&acc)[MT][NT], const float *a_lds, int stride, int g_lds,
+                                              const float4 (&b)[NT]) {
+    float4 a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 32 * stride + 8 * g_lds);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
+        }
+}
+
+// Two named fragment sets, unrolled by two: while one set feeds the MFMAs the load of the other is in
+// flight (written as a rotating single set, hipcc folds the prefetch back into a load-wait-use loop).
+template <int MT, int NT>
 __device__ __forceinline__ void dclr_mma_panel(dclr_f32x16 (&acc)[MT][NT], const float *a_lds, int stride, int g_lds0,
                                                int kg, const float4 *w_lane, int ntile_stride) {
-    float4 bn[NT];
+    float4 b0[NT], b1[NT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) bn[u] = w_lane[(size_t)u * ntile_stride];
-    for (int g = 0; g < kg; ++g) {
-        float4 b[NT];
+    for (int u = 0; u < NT; ++u) b0[u] = w_lane[(size_t)u * ntile_stride];
+    int g = 0;
+    for (; g + 2 <= kg; g += 2) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) b[u] = bn[u];
-        const int gn = g + 1 < kg ? g + 1 : g;
+        for (int u = 0; u < NT; ++u) b1[u] = w_lane[(size_t)u * ntile_stride + (size_t)(g + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);                 // keep the prefetch ahead of the MFMAs it hides behind
+        dclr_mma_step<MT, NT>(acc, a_lds, stride, g_lds0 + g, b0);
+        const int gn = g + 2 < kg ? g + 2 : g + 1;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) bn[u] = w_lane[(size_t)u * ntile_stride + (size_t)gn * 64];
-        float4 a[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-            a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 32 * stride + 8 * (g_lds0 + g));
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].x, b[u].x, acc[t][u], 0, 0, 0);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].y, b[u].y, acc[t][u], 0, 0, 0);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].z, b[u].z, acc[t][u], 0, 0, 0);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t].w, b[u].w, acc[t][u], 0, 0, 0);
-            }
+        for (int u = 0; u < NT; ++u) b0[u] = w_lane[(size_t)u * ntile_stride + (size_t)gn * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        dclr_mma_step<MT, NT>(acc, a_lds, stride, g_lds0 + g + 1, b1);
     }
+    if (g < kg) dclr_mma_step<MT, NT>(acc, a_lds, stride, g_lds0 + g, b0);
 }
 
 // Row of accumulator register r for lane-half h inside a 32-row tile.
@@ -116,32 +127,43 @@ __device__ __forceinline__ void dclr_mma16_group(dclr_f32x4 (&acc)[MT][NT], cons
             }
 }
 
-// Whole K loop for the 16x16x4 layout, with the same one-group-ahead weight prefetch.
+template <int MT, int NT>
+__device__ __forceinline__ void dclr_mma16_step(dclr_f32x4 (&acc)[MT][NT], const float *a_lds, int stride, int g,
+                                                const float4 (&b)[NT]) {
+    float4 a[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 16 * stride + 16 * g);
+    // q outermost: back-to-back MFMAs hit different accumulators (dependent latency 40 > issue 32 cycles)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const float av = q == 0 ? a[t].x : (q == 1 ? a[t].y : (q == 2 ? a[t].z : a[t].w));
+                const float bw = q == 0 ? b[u].x : (q == 1 ? b[u].y : (q == 2 ? b[u].z : b[u].w));
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[t][u], 0, 0, 0);
+            }
+}
+
+// Whole K loop for the 16x16x4 layout, double-buffered like dclr_mma_panel.
 template <int MT, int NT>
 __device__ __forceinline__ void dclr_mma16_panel(dclr_f32x4 (&acc)[MT][NT], const float *a_lds, int stride, int kg,
                                                  const float4 *w_lane, int ntile_stride) {
-    float4 bn[NT];
+    float4 b0[NT], b1[NT];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) bn[u] = w_lane[(size_t)u * ntile_stride];
-    for (int g = 0; g < kg; ++g) {
-        float4 b[NT];
+    for (int u = 0; u < NT; ++u) b0[u] = w_lane[(size_t)u * ntile_stride];
+    int g = 0;
+    for (; g + 2 <= kg; g += 2) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) b[u] = bn[u];
-        const int gn = g + 1 < kg ? g + 1 : g;
+        for (int u = 0; u < NT; ++u) b1[u] = w_lane[(size_t)u * ntile_stride + (size_t)(g + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);                 // keep the prefetch ahead of the MFMAs it hides behind
+        dclr_mma16_step<MT, NT>(acc, a_lds, stride, g, b0);
+        const int gn = g + 2 < kg ? g + 2 : g + 1;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) bn[u] = w_lane[(size_t)u * ntile_stride + (size_t)gn * 64];
-        float4 a[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4 *>(a_lds + t * 16 * stride + 16 * g);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-                    const float av = q == 0 ? a[t].x : (q == 1 ? a[t].y : (q == 2 ? a[t].z : a[t].w));
-                    const float bw = q == 0 ? b[u].x : (q == 1 ? b[u].y : (q == 2 ? b[u].z : b[u].w));
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw, acc[t][u], 0, 0, 0);
-                }
+        for (int u = 0; u < NT; ++u) b0[u] = w_lane[(size_t)u * ntile_stride + (size_t)gn * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        dclr_mma16_step<MT, NT>(acc, a_lds, stride, g + 1, b1);
     }
+    if (g < kg) dclr_mma16_step<MT, NT>(acc, a_lds, stride, g, b0);
 }
