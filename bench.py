@@ -196,6 +196,14 @@ def main():
             kernels = timer.summary()
             sampled_steps = len(range(0, args.steps, LaunchTimer.SAMPLE_EVERY))
 
+            traffic = {}
+            try:        # HBM bytes per launch from the PMC passes kept under profiles/ (collected offline: a
+                        # counter run cannot share a process with the timed region)
+                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
+                    traffic = {k: v['bytes_per_launch_raw'] for k, v in json.load(fh)['kernels'].items()}
+            except (OSError, KeyError, ValueError):
+                pass
+
             def roof(name):
                 bound, units = algorithmic_work(name, cfg, PAIRS_PER_GPU, POINTS)
                 sec = kernels[name]['avg_us'] * 1e-6
@@ -204,7 +212,7 @@ def main():
                 else:
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
                 return {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
-                        'frac': achieved / peak, 'traffic': None, 'avg_us': kernels[name]['avg_us'],
+                        'frac': achieved / peak, 'traffic': traffic.get(name), 'avg_us': kernels[name]['avg_us'],
                         'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
                         'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
 
