@@ -81,6 +81,10 @@ def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int):
     if name.startswith('linear'):
         m, n, kk = (int(v) for v in name[name.index('[') + 1:-1].split('x'))
         return 'mfma', 2.0 * m * n * kk
+    if name == 'head_conv_fused':
+        out = cfg['params']['output']['params']['mlp']
+        dims = [264] + list(out)
+        return 'mfma', 2.0 * pairs * npoint * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
     if name == 'flow_embedding':
         rows = pairs * npoint * k
         return 'mfma', 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5

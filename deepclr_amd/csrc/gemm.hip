@@ -141,6 +141,91 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
         }
 }
 
+// ---- fused conv chain of the pose head ----------------------------------------------------------------
+// One workgroup keeps 32 points through ALL 1x1-conv layers (reference: OutputSimple.forward,
+// deepclr.py:286-287: Conv1dMultiLayer then max over points): activations ping-pong between two LDS
+// buffers, packed weights stream from L2 (every CU walks the layers in step, so a layer's weights are
+// L2-hot), the last layer's column maximum goes out through atomic max. Versus one launch per layer
+// this removes the activation round trips (~50 MB per batch), four launches and the tail effect of the
+// narrow first layers. 8 waves: two per SIMD, so one wave's LDS/L2 waits hide behind the other's MFMAs.
+constexpr int HEAD_WAVES = 8, HEAD_ROWS = 32, HEAD_MAX_LAYERS = 8, HEAD_MAX_WIDTH = 512;
+constexpr int HEAD_BUF = HEAD_ROWS * dclr_lds_stride(HEAD_MAX_WIDTH);        // floats per activation buffer
+
+struct HeadParams {
+    int n_layers;
+    int k[HEAD_MAX_LAYERS];                 // padded input width of layer l (multiple of 8)
+    int n[HEAD_MAX_LAYERS];                 // output width (multiple of 32)
+    const float4 *w[HEAD_MAX_LAYERS];       // packed (n, k) fragments
+    const float *b[HEAD_MAX_LAYERS];
+};
+
+__global__ __launch_bounds__(HEAD_WAVES * 64) void head_fused_kernel(HeadParams prm, const float *__restrict__ x,
+                                                                     int ldx, float *__restrict__ colmax,
+                                                                     int rows_per_group) {
+    __shared__ __attribute__((aligned(16))) float act[2][HEAD_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int m0 = blockIdx.x * HEAD_ROWS;
+
+    // stage the 32 input rows (k[0] columns, 16-byte pieces)
+    {
+        const int stride = dclr_lds_stride(prm.k[0]);
+        const int pieces = prm.k[0] / 4;
+        for (int e = tid; e < HEAD_ROWS * pieces; e += HEAD_WAVES * 64) {
+            const int r = e / pieces, c4 = e - r * pieces;
+            *reinterpret_cast<float4 *>(&act[0][r * stride + 4 * c4]) =
+                *reinterpret_cast<const float4 *>(x + (size_t)(m0 + r) * ldx + 4 * c4);
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < prm.n_layers; ++l) {
+        const float *in = act[l & 1];
+        float *out = act[(l & 1) ^ 1];
+        const int kp = prm.k[l], n = prm.n[l], kg = kp / 8;
+        const int in_stride = dclr_lds_stride(kp), out_stride = dclr_lds_stride(n);
+        const bool last = l == prm.n_layers - 1;
+        const float *a_lds = in + j * in_stride + 4 * h;
+        const int n_tiles = n / 32;
+        // wave w owns column tiles w, w + 8, ...; two at a time share one pass over K
+        for (int t0 = wave; t0 < n_tiles; t0 += 2 * HEAD_WAVES) {
+            const bool two = t0 + HEAD_WAVES < n_tiles;                 // wave-uniform
+            dclr_f32x16 acc[1][2];
+            acc[0][0] = dclr_zero16();
+            acc[0][1] = dclr_zero16();
+            const float4 *w_lane = prm.w[l] + (size_t)t0 * kg * 64 + lane;
+            if (two) {
+                dclr_mma_panel<1, 2>(acc, a_lds, in_stride, 0, kg, w_lane, HEAD_WAVES * kg * 64);
+            } else {
+                dclr_f32x16 acc1[1][1];
+                acc1[0][0] = dclr_zero16();
+                dclr_mma_panel<1, 1>(acc1, a_lds, in_stride, 0, kg, w_lane, 0);
+                acc[0][0] = acc1[0][0];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                const int col = (t0 + u * HEAD_WAVES) * 32 + j;
+                const float bv = prm.b[l][col];
+                if (!last) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        out[dclr_acc_row(r, h) * out_stride + col] = fmaxf(acc[0][u][r] + bv, 0.f);
+                } else {
+                    float mx = 0.f;                                     // ReLU floor
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[0][u][r] + bv);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    if (h == 0)
+                        atomicMax(reinterpret_cast<unsigned int *>(colmax + (size_t)(m0 / rows_per_group) * n + col),
+                                  __float_as_uint(mx));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- FC tail: a handful of rows (one per scan pair) -------------------------------------------------
 // One wave per output column, 4 columns per workgroup. The <= FC_ROWS input rows are staged in LDS
 // once per workgroup; a wave keeps the whole weight row in flight (K/64 coalesced loads issued back
@@ -238,6 +323,30 @@ extern "C" int dclr_linear(int m, int n, int kp, const float *x, int ldx, const 
         hipLaunchKernelGGL((linear_kernel<2>), dim3(m / LIN_BM, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n,
                            kp, x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax,
                            rows_per_group);
+    return dclr_launch_status();
+}
+
+extern "C" int dclr_head_conv_fused(int m, int n_layers, const int *k_host, const int *n_host,
+                                    const float *const *w_packed_host, const float *const *bias_host, const float *x,
+                                    int ldx, float *colmax, int rows_per_group, dclr_stream_t stream) {
+    DCLR_REQUIRE(m > 0 && n_layers >= 1 && k_host && n_host && w_packed_host && bias_host && x && colmax);
+    DCLR_REQUIRE(m % HEAD_ROWS == 0 && rows_per_group > 0 && rows_per_group % HEAD_ROWS == 0 && m % rows_per_group == 0);
+    DCLR_REQUIRE(ldx % 4 == 0 && ldx >= k_host[0] && ((uintptr_t)x & 15) == 0);
+    if (n_layers > HEAD_MAX_LAYERS) return DCLR_E_UNSUPPORTED;
+    HeadParams prm{};
+    prm.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        DCLR_REQUIRE(w_packed_host[l] && bias_host[l] && k_host[l] > 0 && n_host[l] > 0);
+        DCLR_REQUIRE(k_host[l] % 8 == 0 && n_host[l] % 32 == 0 && ((uintptr_t)w_packed_host[l] & 15) == 0);
+        if (l > 0) DCLR_REQUIRE(k_host[l] == n_host[l - 1]);
+        if (k_host[l] > HEAD_MAX_WIDTH || (l + 1 < n_layers && n_host[l] > HEAD_MAX_WIDTH)) return DCLR_E_UNSUPPORTED;
+        prm.k[l] = k_host[l];
+        prm.n[l] = n_host[l];
+        prm.w[l] = reinterpret_cast<const float4 *>(w_packed_host[l]);
+        prm.b[l] = bias_host[l];
+    }
+    hipLaunchKernelGGL(head_fused_kernel, dim3(m / HEAD_ROWS), dim3(HEAD_WAVES * 64), 0, (hipStream_t)stream, prm, x, ldx,
+                       colmax, rows_per_group);
     return dclr_launch_status();
 }
 

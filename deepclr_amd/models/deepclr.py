@@ -11,6 +11,7 @@ and the per-module ``forward`` methods the reference's layer tests call).
 Out of scope here: losses (a ground truth ``y`` raises), backward, batch norm.
 """
 import abc
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -215,8 +216,18 @@ class OutputSimple(DeepCLRModule):
             return layers
         return self._cache.get(list(self.conv.parameters()), build)
 
+    def _fusable(self, layers, rows: int, pairs: int) -> bool:
+        """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512."""
+        return (rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
+                and all(n % 32 == 0 for _, _, n, _ in layers) and all(kp <= 512 for _, _, _, kp in layers)
+                and all(n <= 512 for _, _, n, _ in layers[:-1]))
+
     def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         layers = self._packed()
+        if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
+            g = ops.head_conv_fused(e_rows, layers, pairs)                   # conv chain + max over points
+            g = self.linear(g)
+            return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
         h = e_rows
         for wp, b, n, kp in layers[:-1]:
             h = ops.linear(h, wp, b, n, kp, relu=True, ldy=(n + 7) // 8 * 8)

@@ -235,6 +235,23 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     return y
 
 
+def head_conv_fused(x: torch.Tensor, layers, groups: int) -> torch.Tensor:
+    """x rows (m, ldx); layers = [(w_packed, bias, n, kp), ...] -> (groups, n_last) column maxima of the
+    ReLU'd last layer over each block of m / groups rows (the conv chain of the pose head in one launch)."""
+    x = lib.dev_f32(x, 'x')
+    m, ldx = x.shape
+    nl = len(layers)
+    k_h = (ctypes.c_int * nl)(*[int(l[3]) for l in layers])
+    n_h = (ctypes.c_int * nl)(*[int(l[2]) for l in layers])
+    w_h = (ctypes.c_void_p * nl)(*[l[0].data_ptr() for l in layers])
+    b_h = (ctypes.c_void_p * nl)(*[l[1].data_ptr() for l in layers])
+    out = torch.zeros(groups, layers[-1][2], dtype=torch.float32, device=x.device)
+    _call('dclr_head_conv_fused', 'head_conv_fused', m, nl, ctypes.cast(k_h, ctypes.c_void_p), ctypes.cast(n_h, ctypes.c_void_p),
+          ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p), x.data_ptr(), ldx, out.data_ptr(),
+          m // groups, lib.stream_ptr())
+    return out
+
+
 def knn_rows(f_rows: torch.Tensor, pairs: int, npoint: int, k: int) -> torch.Tensor:
     f_rows = lib.dev_f32(f_rows, 'f_rows')
     idx = torch.empty(pairs, npoint, k, dtype=torch.int32, device=f_rows.device)

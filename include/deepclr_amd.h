@@ -149,6 +149,17 @@ int dclr_pack_weight16(int n_out, int k_in, const float *w, const int32_t *kmap,
 int dclr_linear(int m, int n, int kp, const float *x, int ldx, const float *w_packed, const float *bias,
                 int relu, float *y, int ldy, float *colmax, int rows_per_group, dclr_stream_t stream);
 
+/* The whole 1x1-conv chain of the pose head in one launch (reference: OutputSimple.forward,
+ * /root/reference/deepclr/models/deepclr.py:286-287): x rows (m, ldx) -> n_layers x [affine + ReLU] ->
+ * column maxima per group of rows_per_group rows into colmax (m / rows_per_group, n_last), which the caller
+ * zero-fills. k_host / n_host: padded input / output width per layer (k multiple of 8, n multiple of 32,
+ * k[l] == n[l-1], hidden widths <= 512); w_packed_host[l]: dclr_pack_weight(n[l], ., kp = k[l], np = n[l]);
+ * the four *_host arrays are HOST arrays of sizes / device pointers read at call time. m and
+ * rows_per_group multiples of 32. */
+int dclr_head_conv_fused(int m, int n_layers, const int *k_host, const int *n_host,
+                         const float *const *w_packed_host, const float *const *bias_host, const float *x,
+                         int ldx, float *colmax, int rows_per_group, dclr_stream_t stream);
+
 /* kNN on feature rows: queries = template clouds 0..pairs-1, candidates = source clouds
  * pairs..2*pairs-1 of F (xyz at columns 64..66). knn_idx (pairs, npoint, k) i32 local candidate
  * indices, ordered as dclr_knn orders them. */
