@@ -279,3 +279,34 @@ def test_full_size_kitti_batch_properties_and_oracle_pair():
     y_o = orc(torch.from_numpy(x_np[[0, 8]]))
     _close(y[:1], y_o)
     assert pose_delta(_mats(y[:1]), np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])) < 1e-4
+
+
+@pytest.mark.parametrize('kind,n,pairs', [('modelnet', 2048, 6), ('kitti', 65536, 1)])
+def test_other_baseline_configs_against_oracle(kind, n, pairs):
+    """BASELINE.json configs 4 (ModelNet40, 2048 pts, many pairs per batch) and 5 (dense 65536-pt clouds) at a
+    batch size the oracle finishes in seconds; the full-size runs differ only in the batch count (pairs are
+    independent, checked in test_full_size_kitti_batch_properties_and_oracle_pair)."""
+    cfg = synthetic.model_cfg(kind)
+    sd = synthetic.random_state_dict(cfg, seed=31)
+    model, orc = _models(cfg, sd)
+    x_cpu = torch.from_numpy(synthetic.make_batch(kind, pairs, n, first_pair=100))
+    with torch.no_grad():
+        y, _, _ = model(x_cpu.to(DEV))
+    y_o = orc(x_cpu)
+    _close(y, y_o)
+    mats_o = np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])
+    assert pose_delta(_mats(y), mats_o) < 1e-4
+
+
+def test_pipelined_runner_matches_plain_forward():
+    from deepclr_amd.pipeline import PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=2))
+    batches = [torch.from_numpy(synthetic.make_batch('kitti', 2, 4096, first_pair=10 * i)).to(DEV) for i in range(5)]
+    with torch.no_grad():
+        want = [model(b)[0] for b in batches]
+    for ahead in ('sample', 'features'):
+        got = list(PipelinedForward(model, depth=2, ahead=ahead).run(batches))
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
