@@ -28,7 +28,7 @@ from deepclr_amd import ops, synthetic                      # noqa: E402
 from deepclr_amd.config import model_config_from_dict       # noqa: E402
 from deepclr_amd.labels import LabelType                    # noqa: E402
 from deepclr_amd.models import build_model                  # noqa: E402
-from deepclr_amd.pipeline import PipelinedForward           # noqa: E402
+from deepclr_amd.pipeline import PipelinedForward, PipelinedSequence           # noqa: E402
 
 PAIRS_PER_GPU = 8
 POINTS = 16384
@@ -41,10 +41,12 @@ class LaunchTimer:
 
     SAMPLE_EVERY = 4       # bracket the launches of every 4th step only: the events themselves cost ~10 %
 
-    def __init__(self):
+    def __init__(self, sample_every=None):
         self.spans = []
         self.main_stream = torch.cuda.current_stream().cuda_stream
         self.step = 0
+        if sample_every is not None:
+            self.SAMPLE_EVERY = sample_every
 
     def next_step(self):
         self.step += 1
@@ -72,7 +74,7 @@ class LaunchTimer:
                 for k, v in acc.items()}
 
 
-def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int):
+def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int, clouds: int):
     """(bound, units) per launch: flops for the MFMA kernels, bytes for the memory-shaped ones.
     Figures are stated per scan pair in DESIGN.md section 'Kernels and rooflines'."""
     sa = cfg['params']['cloud_features']['params']
@@ -89,9 +91,9 @@ def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int):
         rows = pairs * npoint * k
         return 'mfma', 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5
     if name == 'fps_clouds':        # reads every cloud once, writes the indices
-        return 'hbm', 2.0 * pairs * (n_points * c * 4 + npoint * 4)
+        return 'hbm', clouds * (n_points * c * 4 + npoint * 4)
     if name == 'sa_msg_fused':      # reads every cloud once + index list, writes 68-float rows
-        return 'hbm', 2.0 * pairs * (n_points * c * 4 + npoint * 4 + npoint * 68 * 4)
+        return 'hbm', clouds * (n_points * c * 4 + npoint * 4 + npoint * 68 * 4)
     if name == 'knn_rows':
         return 'hbm', pairs * npoint * (2 * 68 * 4 + k * 4)
     return 'hbm', 0.0
@@ -128,6 +130,9 @@ def main():
     ap.add_argument('--no-launch-timer', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--no-overlap', action='store_true', help='run sampling in line instead of batches ahead')
     ap.add_argument('--depth', type=int, default=3, help='batches whose sampling runs ahead on side streams')
+    ap.add_argument('--sequence', action='store_true',
+                    help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
+                         'one sequence = 16 pairs, every frame sampled and abstracted once')
     ap.add_argument('--ahead', default='features', choices=['sample', 'features'], help='stages run ahead')
     args = ap.parse_args()
 
@@ -150,12 +155,22 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     x = torch.from_numpy(synthetic.make_batch('kitti', PAIRS_PER_GPU, POINTS, first_pair=rank * PAIRS_PER_GPU)).to(dev)
-    gathered = torch.empty(world * PAIRS_PER_GPU, 8, device=dev) if world > 1 else None
-
-    runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead)
+    
+    pairs_per_step = PAIRS_PER_GPU
+    if args.sequence:
+        if args.no_overlap:
+            raise SystemExit('bench.py: --sequence runs through the pipelined runner')
+        pairs_per_step = x.shape[0]
+        runner = PipelinedSequence(model, depth=args.depth, ahead=args.ahead)
+        runner.prefetch(x)
+        runner.step(x)                       # first chunk: caches the frame the timed chunks start from
+    else:
+        runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead)
     if runner is not None:
         for _ in range(args.depth):
             runner.prefetch(x)
+
+    gathered = torch.empty(world * pairs_per_step, 8, device=dev) if world > 1 else None
 
     def step():
         if runner is not None:
@@ -186,6 +201,23 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    alone = None
+    if timer is not None and rank == 0:
+        # second, untimed pass: the same launches one after another on one stream, so that each kernel's
+        # duration is its own (in the timed region they share the CUs with the sampler running ahead)
+        solo = LaunchTimer(sample_every=1)
+        ops.TIMER = solo
+        with torch.no_grad():
+            for _ in range(6):
+                if args.sequence:
+                    f_rows = model.cloud_feature_rows(x)
+                    rows, pairs, _ = model.sequence_rows(f_rows, x.shape[0], f_rows[-model.npoint:])
+                    model.merge_rows(rows, pairs)
+                else:
+                    model(x)
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        alone = solo.summary()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -193,7 +225,7 @@ def main():
 
     result = None
     if rank == 0:
-        pairs_total = world * PAIRS_PER_GPU * args.steps
+        pairs_total = world * pairs_per_step * args.steps
         roofline, kernels = None, None
         rooflines = None
         if timer is not None:
@@ -209,14 +241,17 @@ def main():
                 pass
 
             def roof(name):
-                bound, units = algorithmic_work(name, cfg, PAIRS_PER_GPU, POINTS)
+                bound, units = algorithmic_work(name, cfg, pairs_per_step, POINTS, x.shape[0])
                 sec = kernels[name]['avg_us'] * 1e-6
                 if bound == 'mfma':
                     achieved, peak, unit = units / sec / 1e12, FP32_MATRIX_PEAK_TFLOPS, 'TFLOP/s'
                 else:
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
+                solo_us = alone[name]['avg_us'] if alone and name in alone else None
                 return {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'unit': unit,
                         'frac': achieved / peak, 'traffic': traffic.get(name), 'avg_us': kernels[name]['avg_us'],
+                        'alone_us': solo_us,
+                        'frac_alone': None if solo_us is None else achieved / peak * kernels[name]['avg_us'] / solo_us,
                         'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
                         'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
 
@@ -230,10 +265,13 @@ def main():
             'metric': 'scan-pairs/sec (2x16384 pts)', 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'KITTI-sized scan pairs, 2x16384 pts x 4 ch, {} pairs/GPU/step '
-                                   '(BASELINE.json configs[1]); kitti_00-06 architecture, seeded random weights'
-                                   .format(PAIRS_PER_GPU),
-                       'pairs_per_gpu': PAIRS_PER_GPU, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world,
+            'config': {'workload': ('odometry chunks of {} consecutive KITTI-sized frames (16384 pts x 4 ch) = {} pairs'
+                                    '/GPU/step, each frame sampled once; NOT the BASELINE metric'
+                                    if args.sequence else
+                                    'KITTI-sized scan pairs, 2x16384 pts x 4 ch, {1} pairs/GPU/step '
+                                    '(BASELINE.json configs[1])').format(x.shape[0], pairs_per_step)
+                                   + '; kitti_00-06 architecture, seeded random weights',
+                       'pairs_per_gpu': pairs_per_step, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth},
             'roofline': roofline,
         }
@@ -244,9 +282,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             import oracle
             from oracle import labels as olabels
-            y_ref = oracle.build_oracle_model(cfg, sd)(x[[0, PAIRS_PER_GPU]].cpu())
+            first = [0, 1] if args.sequence else [0, PAIRS_PER_GPU]          # clouds of output row `row`
+            row = 1 if args.sequence else 0
+            y_ref = oracle.build_oracle_model(cfg, sd)(x[first].cpu())
             lt = LabelType.POSE3D_DUAL_QUAT
-            result['pose_delta_vs_oracle'] = float(np.abs(lt.to_matrix(y[0].cpu().numpy())
+            result['pose_delta_vs_oracle'] = float(np.abs(lt.to_matrix(y[row].cpu().numpy())
                                                           - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max())
             result['cpu_baseline'] = cpu_baseline(cfg, sd)
         print(json.dumps(result), flush=True)

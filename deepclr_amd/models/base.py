@@ -102,6 +102,24 @@ class ModelInferenceHelper:
             y, _, _ = self._model.forward(x.contiguous(), is_feat=False)
         return y
 
+    def predict_sequence(self, frames: torch.Tensor) -> torch.Tensor:
+        """Sequential mode over a chunk of consecutive frames (T, N, C): the same poses T calls of
+        predict(frame) return (the first being None on a fresh state), with every frame's features computed
+        once and in one batch. Returns (T, label_dim), or (T-1, label_dim) when no frame was cached."""
+        if not self._is_sequential:
+            raise RuntimeError("predict_sequence needs a sequential helper.")
+        if frames.shape[2] < self._input_dim:
+            raise RuntimeError("Wrong point dimension in source.")
+        with torch.no_grad():
+            feats = self._model.cloud_features(frames[:, :, :self._input_dim].contiguous())
+            if self._state is not None:
+                feats = torch.cat((self._state.unsqueeze(0), feats))
+            self._state = feats[-1]
+            if feats.shape[0] < 2:
+                return feats.new_empty(0, getattr(self._model, 'label_dim', 0))
+            y, _, _ = self._model.forward(torch.cat((feats[:-1], feats[1:])), is_feat=True)
+        return y
+
     @staticmethod
     def stack(template: torch.Tensor, source: torch.Tensor) -> torch.Tensor:
         """Two clouds -> batch (2, N, C); the larger one is randomly subsampled to the smaller size."""

@@ -342,6 +342,21 @@ class DeepCLR(BaseModel):
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         return self._merge_layers[1].forward_rows(e_rows, pairs)
 
+    @property
+    def label_dim(self) -> int:
+        return self._merge_layers[1].output_dim()
+
+    def sequence_rows(self, f_rows: torch.Tensor, frames: int, carry: Optional[torch.Tensor] = None):
+        """Rows F of `frames` consecutive clouds (+ the rows of the frame before them, if any) -> the pair
+        layout merge_rows() takes: templates = every frame but the last, sources = every frame but the first.
+        Returns (rows, pairs, rows of the last frame)."""
+        v = f_rows.view(frames, self.npoint, f_rows.shape[-1])
+        if carry is not None:
+            v = torch.cat((carry.view(1, self.npoint, -1), v))
+        pairs = v.shape[0] - 1
+        rows = torch.cat((v[:-1], v[1:])).view(2 * pairs * self.npoint, -1) if pairs > 0 else None
+        return rows, pairs, v[-1].clone()
+
     @staticmethod
     def _augment(x: torch.Tensor, m: torch.Tensor) -> None:
         """In-place homogeneous transform of the point columns (reference: deepclr.py:512-514)."""

@@ -69,7 +69,10 @@ class PipelinedForward:
                 f_rows = ready
             else:
                 f_rows = self._model.cloud_feature_rows(x, ready)
-            return self._model.merge_rows(f_rows, x.shape[0] // 2)
+            return self._dense(f_rows, x)
+
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        return self._model.merge_rows(f_rows, x.shape[0] // 2)
 
     def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
         it = iter(batches)
@@ -91,3 +94,24 @@ class PipelinedForward:
             refill()
             started = self.in_flight()
             yield self.step(cur, list(window)[started:])
+
+
+class PipelinedSequence(PipelinedForward):
+    """Odometry over one scan sequence, fed in chunks of T consecutive frames (T, N, C): every frame is
+    sampled and abstracted ONCE and serves first as source, then as template of the next pair
+    (the reference's sequential mode, /root/reference/deepclr/models/base.py:97-112, caches one frame and
+    runs one pair per call). step() returns the poses frame[i-1] -> frame[i] for the chunk: (T, label_dim),
+    or (T-1, label_dim) for the first chunk after reset()."""
+
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features'):
+        super().__init__(model, depth, ahead)
+        self._carry: Optional[torch.Tensor] = None
+
+    def reset(self) -> None:
+        self._carry = None
+
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        pair_rows, pairs, self._carry = self._model.sequence_rows(f_rows, x.shape[0], self._carry)
+        if pairs == 0:
+            return f_rows.new_empty(0, self._model.label_dim)
+        return self._model.merge_rows(pair_rows, pairs)

@@ -310,3 +310,26 @@ def test_pipelined_runner_matches_plain_forward():
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+def test_sequence_mode_computes_each_frame_once_and_matches_pairwise_calls():
+    """Reference sequential mode (models/base.py:97-112): frame t is the source of pair (t-1, t) and the template
+    of pair (t, t+1). The chunked runner must return exactly what per-frame predict() calls return."""
+    from deepclr_amd.models import ModelInferenceHelper
+    from deepclr_amd.pipeline import PipelinedSequence
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=4)
+    model, orc = _models(cfg, sd)
+    clouds = synthetic.make_batch('kitti', 3, 4096, first_pair=50)             # 6 clouds, used as 6 "frames"
+    frames = torch.from_numpy(np.ascontiguousarray(clouds[[0, 3, 1, 4, 2, 5]])).to(DEV)
+    one = ModelInferenceHelper(model, is_sequential=True)
+    assert one.predict(frames[0]) is None
+    want = torch.stack([one.predict(frames[i]) for i in range(1, 6)])
+    chunked = ModelInferenceHelper(model, is_sequential=True)
+    got = torch.cat((chunked.predict_sequence(frames[:2]), chunked.predict_sequence(frames[2:])))
+    assert torch.equal(got, want)
+    assert torch.equal(chunked.predict(frames[0]), one.predict(frames[0]))      # the cached frame carries on
+    piped = torch.cat(list(PipelinedSequence(model, depth=2).run([frames[:1], frames[1:4], frames[4:]])))
+    assert torch.equal(piped, want)
+    y_o = orc(torch.stack((frames[2], frames[3])).cpu())                        # pair (frame 2 -> frame 3)
+    _close(want[2:3], y_o)
