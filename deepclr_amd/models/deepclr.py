@@ -217,8 +217,10 @@ class OutputSimple(DeepCLRModule):
         return self._cache.get(list(self.conv.parameters()), build)
 
     def _fusable(self, layers, rows: int, pairs: int) -> bool:
-        """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512."""
-        return (rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
+        """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512. Its grid is
+        rows / 32 workgroups, one per CU: below half the chip (single pairs, the reference's own batch size) the
+        per-layer kernels, whose grids also split the output columns, finish sooner (84 vs 142 us at one pair)."""
+        return (rows >= 4096 and rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
                 and all(n % 32 == 0 for _, _, n, _ in layers) and all(kp <= 512 for _, _, _, kp in layers)
                 and all(n <= 512 for _, _, n, _ in layers[:-1]))
 

@@ -256,6 +256,31 @@ def test_linear_kernel_against_torch():
         _close(ops.linear(x.to(DEV), wp, None, n, kp, relu=False), raw)
 
 
+def test_fused_head_chain_equals_layer_by_layer_kernels():
+    """Batches of >= 4 pairs run the five head layers in one launch, smaller ones layer by layer: same k order in
+    both, so the results must be identical, not just close."""
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=7))
+    head = model._merge_layers[1]
+    layers = head._packed()
+    rows, pairs = 4096, 4
+    e = torch.zeros(rows, ops.E_STRIDE, device=DEV)
+    e[:, :259] = torch.from_numpy(np.random.default_rng(3).normal(size=(rows, 259)).astype(np.float32)).to(DEV)
+    assert head._fusable(layers, rows, pairs) and not head._fusable(layers, rows // 2, pairs // 2)
+    fused = ops.head_conv_fused(e, layers, pairs)
+    h = e
+    for wp, b, n, kp in layers[:-1]:
+        h = ops.linear(h, wp, b, n, kp, relu=True, ldy=(n + 7) // 8 * 8)
+    wp, b, n, kp = layers[-1]
+    plain = ops.linear(h, wp, b, n, kp, relu=True, colmax_groups=pairs)
+    assert torch.equal(fused, plain)
+    want = e[:, :259].double().cpu()
+    want = torch.cat((want[:, 256:259], want[:, :256]), dim=1)                 # reference column order [xyz | feat]
+    for w, bias in head.conv.affine_params():
+        want = torch.relu(want @ w.detach().double().cpu().reshape(w.shape[0], -1).t() + bias.detach().double().cpu())
+    _close(fused, want.view(pairs, rows // pairs, -1).max(dim=1).values.float())
+
+
 def test_full_size_kitti_batch_properties_and_oracle_pair():
     """BASELINE.json config 2 (B=8, N=16384): properties on the whole batch, oracle parity on pair 0."""
     cfg = synthetic.model_cfg('kitti')
