@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/eval_sequence.txt + eval_expected.npz with the REFERENCE's evaluation code.
+
+Runs only in the build container (needs /root/reference). Loads the reference's
+deepclr/evaluation/{data,metrics,evaluator}.py as a package by path. transforms3d is absent from this image;
+it is needed only for the euler-angle error *vectors*, which deepclr_amd.evaluation does not provide, so an
+inert placeholder is registered for it (affines.decompose / euler.mat2euler return zeros) and the `vec` fields
+are not exported. What gets pinned: the 26-column result-file format, pose chaining and path lengths, the KITTI
+step errors and the KITTI segment errors.
+
+Usage:  python tests/golden/make_eval_golden.py  [--reference /root/reference]
+"""
+import argparse
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    mx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    my = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    mz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return mz @ my @ mx
+
+
+def trajectory(n, seed):
+    """A drive of n steps (~1.3 m each, gentle turns) and a noisy estimate of it."""
+    rng = np.random.default_rng(seed)
+    gt, pred = [], []
+    for i in range(n):
+        m = np.eye(4)
+        m[:3, :3] = _rot(*(rng.normal(0, [0.002, 0.002, 0.02])))
+        m[:3, 3] = [1.3 + rng.normal(0, 0.1), rng.normal(0, 0.02), rng.normal(0, 0.02)]
+        e = np.eye(4)
+        e[:3, :3] = _rot(*(rng.normal(0, [0.001, 0.001, 0.003])))
+        e[:3, 3] = rng.normal(0, [0.03, 0.01, 0.01])
+        gt.append(m)
+        pred.append(m @ e)
+    stamps = 0.1 * np.arange(n) + 1.5e9
+    times = rng.uniform(0.5, 3.0, size=n)
+    return stamps, pred, gt, times
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reference', default='/root/reference')
+    args = ap.parse_args()
+
+    t3d = types.ModuleType('transforms3d')
+    t3d.affines = types.SimpleNamespace(decompose=lambda m: (np.zeros(3), np.eye(3), np.ones(3), np.zeros(3)))
+    t3d.euler = types.SimpleNamespace(mat2euler=lambda r, axes='sxyz': (0.0, 0.0, 0.0))
+    sys.modules['transforms3d'] = t3d
+    import matplotlib
+    matplotlib.use('Agg')
+    pkg = types.ModuleType('refeval')
+    pkg.__path__ = [os.path.join(args.reference, 'deepclr', 'evaluation')]
+    sys.modules['refeval'] = pkg
+    data = importlib.import_module('refeval.data')
+    evaluator = importlib.import_module('refeval.evaluator')
+
+    stamps, pred, gt, times = trajectory(700, seed=11)
+    seq = data.Sequence()
+    for s, p, g, t in zip(stamps, pred, gt, times):
+        seq.add_transforms(s, p, g, t)
+    seq.write(os.path.join(HERE, 'eval_sequence.txt'))
+
+    steps = evaluator._step_errors(seq)
+    segs = evaluator._segment_errors(seq)
+    np.savez_compressed(
+        os.path.join(HERE, 'eval_expected.npz'),
+        poses_pred=np.array(seq.prediction.poses), poses_gt=np.array(seq.ground_truth.poses),
+        distances_gt=np.array(seq.ground_truth.distances, dtype=np.float64),
+        step_translation=np.array([e.translation.kitti for e in steps]),
+        step_translation_rmse=np.array([e.translation.rmse for e in steps]),
+        step_rotation=np.array([e.rotation.kitti for e in steps]),
+        step_rotation_chordal=np.array([e.rotation.chordal for e in steps]),
+        step_time=np.array([e.time for e in steps]),
+        seg_first=np.array([e.first_frame for e in segs]), seg_length=np.array([e.segment_length for e in segs]),
+        seg_speed=np.array([e.speed for e in segs]),
+        seg_translation=np.array([e.translation.kitti for e in segs]),
+        seg_rotation=np.array([e.rotation.kitti for e in segs]))
+    print('wrote eval_sequence.txt ({} rows), eval_expected.npz ({} segments)'.format(len(stamps), len(segs)))
+
+
+if __name__ == '__main__':
+    main()
