@@ -185,6 +185,17 @@ int dclr_flow_embedding_fused(int pairs, int npoint, int k, float radius, const 
 int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act, float *y,
             dclr_stream_t stream);
 
+/* ---- scan preparation (reference: CPU transforms run per sample before the model) -----------------------
+ * One order-preserving pass over a raw scan raw (n_raw, c_raw): keep rows start, start+nth, ...
+ * (SystematicErasing, /root/reference/deepclr/data/transforms/transforms.py:244-268), of those the rows with
+ * min_range <= max(|x|,|y|) <= max_range (RangeSelection, transforms.py:90-110; min 0 and max +inf = keep all),
+ * and of each row the first c_out columns (TruncateDimension, transforms.py:271-282).
+ * out: capacity ceil((n_raw-start)/nth) rows of c_out floats; count: 1 int (rows written);
+ * block_counts: scratch of dclr_prepare_cloud_blocks(n_raw, nth, start) ints. */
+int dclr_prepare_cloud_blocks(int n_raw, int nth, int start);
+int dclr_prepare_cloud(int n_raw, int c_raw, const float *raw, int nth, int start, float min_range, float max_range,
+                       int c_out, float *out, int32_t *count, int32_t *block_counts, dclr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
