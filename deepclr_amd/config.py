@@ -51,6 +51,14 @@ class Config(OrderedDict):
     def dump(self) -> str:
         return yaml.safe_dump(_plain(self), sort_keys=False)
 
+    def copy(self) -> 'Config':                      # deep, like the reference's Config.copy (scripts/inference.py:64)
+        return Config.from_dict(self.dict())
+
+    def write_file(self, filename: str, **_flags: Any) -> None:
+        """YAML dump (reference: Config.write_file; its invalid=/internal= filters have nothing to act on here)."""
+        with open(filename, 'w') as stream:
+            stream.write(self.dump())
+
 
 def _plain(x: Any) -> Any:
     if isinstance(x, dict):

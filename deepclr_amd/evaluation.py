@@ -15,6 +15,9 @@ from collections import OrderedDict
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
+import yaml
+
+from .config import Config, ConfigEnum
 
 STEP_SIZE = 10                                            # evaluator.py:18 (one start frame per second at 10 Hz)
 SEGMENT_LENGTHS = (100, 200, 300, 400, 500, 600, 700, 800)   # evaluator.py:19, metres
@@ -217,3 +220,32 @@ class Evaluator:
                 'time_mean [ms]': mean(steps, 'time'),
                 'kitti_translation [%]': mean(segs, 'translation', 100.0),
                 'kitti_rotation [deg/m]': mean(segs, 'rotation', 180.0 / np.pi)}
+
+
+class DatasetType(ConfigEnum):
+    """Dataset kinds a scenario may name (/root/reference/deepclr/data/datasets/build.py:13-17)."""
+    GENERIC = 1
+    KITTI_ODOMETRY_VELODYNE = 2
+    MODELNET40 = 3
+
+
+def load_scenario(filename: str, with_method: bool = False) -> Config:
+    """Scenario file of scripts/inference.py (/root/reference/deepclr/evaluation/scenario.py:6-33): `name`,
+    `dataset_type`, `sequential`, `data` {sequence name: path, environment variables expanded}, optional `method`
+    {name, params}."""
+    with open(filename, 'r') as stream:
+        cfg = Config.from_dict(yaml.safe_load(stream) or {})
+    missing = [k for k in ('name', 'dataset_type', 'sequential', 'data') if cfg.get(k) is None]
+    method = cfg.get('method') or Config()
+    if with_method and method.get('name') is None:
+        missing.append('method.name')
+    if missing:
+        raise RuntimeError("Configuration is not valid, missing required parameters.")
+    cfg.method = Config.from_dict({'name': method.get('name'), 'params': dict(method.get('params') or {})})
+    cfg.dataset_type = DatasetType.create(cfg.dataset_type)
+    for name, path in cfg.data.items():
+        full = os.path.realpath(os.path.expandvars(os.path.expanduser(path)))
+        if '%' in full or '$' in full:
+            raise RuntimeError("Could not replace a variable in path '{}'".format(full))
+        cfg.data[name] = full
+    return cfg

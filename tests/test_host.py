@@ -119,3 +119,37 @@ def test_synthetic_inputs_are_deterministic():
     assert not np.array_equal(a[0], synthetic.make_batch('kitti', 1, 128, first_pair=1)[0])
     m = synthetic.make_batch('modelnet', 1, 64)
     assert m.shape == (2, 64, 3) and np.abs(m).max() < 1.5
+
+
+def test_reference_import_names_resolve_to_this_package(tmp_path):
+    """What scripts/inference.py:9-13 and scripts/timing.py:6-10 import must exist under the reference's names."""
+    import deepclr_amd.models
+    from deepclr.config import load_model_config, load_config, Config, Mode                      # noqa: F401
+    from deepclr.data import create_input_dataflow, make_data_loader, LabelType                  # noqa: F401
+    from deepclr.evaluation import load_scenario, Evaluator
+    from deepclr.models import load_trained_model, build_model, ModelInferenceHelper              # noqa: F401
+    from deepclr.utils.logging import create_logger
+    from deepclr.utils.tensor import prepare_tensor
+    assert ModelInferenceHelper is deepclr_amd.models.ModelInferenceHelper
+    with pytest.raises(RuntimeError):
+        create_input_dataflow('kitti_odometry_velodyne', 'x.lmdb', shuffle=False)
+    with pytest.raises(RuntimeError):
+        load_config('cfg.yaml', Mode.TEST)
+    assert prepare_tensor(torch.ones(2), device='cpu').device.type == 'cpu'
+    log = create_logger('test_host_logger')
+    assert log is create_logger('test_host_logger') and len(log.handlers) <= 1     # never attached twice
+    scen = tmp_path / 'scen.yaml'
+    scen.write_text("name: kitti_07\ndataset_type: kitti_odometry_velodyne\nsequential: True\n"
+                    "data:\n  '07': '${HOME}/odometry/07.lmdb'\n")
+    cfg = load_scenario(str(scen), with_method=False)
+    assert cfg.sequential is True and cfg.dataset_type.name == 'KITTI_ODOMETRY_VELODYNE'
+    assert '$' not in cfg.data['07'] and cfg.data['07'].endswith('odometry/07.lmdb')
+    eval_cfg = cfg.copy()                                         # scripts/inference.py:64-70
+    eval_cfg.method.name = 'DEEPCLR'
+    eval_cfg.method.params.model_name = 'kitti_00-06'
+    eval_cfg.write_file(str(tmp_path / 'scenario.yaml'), invalid=True, internal=True)
+    assert 'model_name: kitti_00-06' in (tmp_path / 'scenario.yaml').read_text()
+    assert cfg.method.name is None
+    with pytest.raises(RuntimeError):
+        load_scenario(str(scen), with_method=True)
+    assert isinstance(Evaluator(), deepclr_amd.evaluation.Evaluator)
