@@ -1,0 +1,240 @@
+// Fused flow embedding on split-fp16 MFMA (mma16f.h).
+//
+// Same operator and workgroup shape as flow_kernel in flow.hip (reference: MotionEmbeddingBase.forward,
+// /root/reference/deepclr/models/deepclr.py:201-231): 4 template points per workgroup, row tile t =
+// neighbours 4t..4t+3 of the 4 points, layer 1 by linearity on the vector pipe. Layers 2 and 3 run on
+// v_mfma_f32_16x16x32_f16 with hi/lo-split operands (three instructions per product, f32 accumulation):
+//   layer 2 computes W2 * H1^T -- accumulator lane = neighbour row, registers = 4 consecutive channels,
+//           split and stored in place as half-octets of layer 3's input;
+//   layer 3 computes H2 * W3^T -- lane = channel, lane-quarter = template point, registers = its 4
+//           neighbours of the tile, so mask + max over the k neighbours stays in registers.
+#include "mma16f.h"
+
+namespace {
+
+constexpr int F16_G = 4;                        // template points per workgroup
+constexpr int F16_C = 128;                      // hidden width of layers 1 and 2
+constexpr int F16_OUT = 256;
+constexpr int F16_STRIDE = dclr_split_stride(F16_C);    // 528 bytes per row
+constexpr int F16_KG = F16_C / 32;              // 4 k-steps of 32
+
+// One pass over K for T row tiles x 2 channel tiles. TRANSPOSED: weights are the A operand.
+template <int T, bool TRANSPOSED>
+__device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4 (&acc2)[T][2], const char *a_lane,
+                                             const float4 *wh_lane, const float4 *wl_lane, int tile_stride) {
+    dclr_h8 h0[2], l0[2], h1[2], l1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride);
+        l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride);
+    }
+    auto step = [&](int g, const dclr_h8 (&wh)[2], const dclr_h8 (&wl)[2]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const char *p = a_lane + t * 16 * F16_STRIDE + 128 * g;
+            const dclr_h8 ah = dclr_lds_h8(p), al = dclr_lds_h8(p + 16);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc[t][u] = TRANSPOSED ? dclr_mfma16(wh[u], ah, acc[t][u]) : dclr_mfma16(ah, wh[u], acc[t][u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc2[t][u] = TRANSPOSED ? dclr_mfma16(wl[u], ah, acc2[t][u]) : dclr_mfma16(ah, wl[u], acc2[t][u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc2[t][u] = TRANSPOSED ? dclr_mfma16(wh[u], al, acc2[t][u]) : dclr_mfma16(al, wh[u], acc2[t][u]);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < F16_KG; g += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            h1[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
+            l1[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        step(g, h0, l0);
+        if (g + 2 < F16_KG) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
+                l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        step(g + 1, h1, l1);
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, int npoint, int k, float radius,
+                                                     const float *__restrict__ f_rows,
+                                                     const int32_t *__restrict__ knn_idx,
+                                                     const float *__restrict__ pt, const float *__restrict__ ps,
+                                                     const float *__restrict__ w1a, const float *__restrict__ b1,
+                                                     const float4 *__restrict__ w2p, const float *__restrict__ b2,
+                                                     const float4 *__restrict__ w3p, const float *__restrict__ b3,
+                                                     float *__restrict__ e_rows) {
+    __shared__ __attribute__((aligned(16))) char tile[T * 16 * F16_STRIDE];
+    __shared__ uint32_t vbits[F16_G];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, c16 = lane & 15;
+    const size_t total = (size_t)pairs * npoint;
+    const size_t g0 = (size_t)blockIdx.x * F16_G;
+
+    // ---- phase A: wave w builds the layer-1 rows of template point g0 + w (lane = channels 2l, 2l+1) ----
+    {
+        const int p = wave;
+        const size_t gp = g0 + p;
+        const bool live = gp < total;                                   // wave-uniform
+        uint32_t bits = 0;
+        int s_done = 0;
+        // channels 2 lane, 2 lane + 1 sit in octet lane / 4 at half positions 2 (lane % 4), + 1
+        char *const slot = tile + 32 * (lane >> 2) + 4 * (lane & 3);
+        if (live) {
+            const size_t pair = gp / npoint;
+            const float *trow = f_rows + gp * DCLR_F_STRIDE;             // template clouds come first
+            const float tx = trow[64], ty = trow[65], tz = trow[66];
+            const float2 ptv = *reinterpret_cast<const float2 *>(pt + gp * F16_C + 2 * lane);
+            const float2 bv = *reinterpret_cast<const float2 *>(b1 + 2 * lane);
+            const float wa0 = w1a[(2 * lane) * 3 + 0], wa1 = w1a[(2 * lane) * 3 + 1], wa2 = w1a[(2 * lane) * 3 + 2];
+            const float wb0 = w1a[(2 * lane + 1) * 3 + 0], wb1 = w1a[(2 * lane + 1) * 3 + 1],
+                        wb2 = w1a[(2 * lane + 1) * 3 + 2];
+            const float base0 = ptv.x + bv.x, base1 = ptv.y + bv.y;
+            const int my_nb = lane < k ? knn_idx[gp * k + lane] : 0;
+            const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
+#pragma unroll 4
+            for (int s = 0; s < k; ++s) {
+                const int nb = __builtin_amdgcn_readlane(my_nb, s);
+                const float *srow = f_rows + (src0 + nb) * DCLR_F_STRIDE;
+                const float dx = srow[64] - tx, dy = srow[65] - ty, dz = srow[66] - tz;
+                const float2 psv = *reinterpret_cast<const float2 *>(ps + (pair * npoint + nb) * F16_C + 2 * lane);
+                float v0 = base0 + psv.x, v1 = base1 + psv.y;
+                v0 = fmaf(wa0, dx, v0); v0 = fmaf(wa1, dy, v0); v0 = fmaf(wa2, dz, v0);
+                v1 = fmaf(wb0, dx, v1); v1 = fmaf(wb1, dy, v1); v1 = fmaf(wb2, dz, v1);
+                dclr_h2 hi, lo;
+                _Float16 a, b;
+                dclr_split(fmaxf(v0, 0.f), a, b); hi[0] = a; lo[0] = b;
+                dclr_split(fmaxf(v1, 0.f), a, b); hi[1] = a; lo[1] = b;
+                const int row = (s >> 2) * 16 + 4 * p + (s & 3);
+                *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE) = hi;
+                *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE + 16) = lo;
+                const float norm = sqrtf(dx * dx + dy * dy + dz * dz);
+                if (!(radius > 0.f) || norm < radius) bits |= 1u << s;
+            }
+            s_done = k;
+        }
+        for (int s = s_done; s < 4 * T; ++s) {                          // padding rows (k % 4 != 0, or no point)
+            const int row = (s >> 2) * 16 + 4 * p + (s & 3);
+            *reinterpret_cast<uint32_t *>(slot + row * F16_STRIDE) = 0u;
+            *reinterpret_cast<uint32_t *>(slot + row * F16_STRIDE + 16) = 0u;
+        }
+        if (lane == 0) vbits[p] = bits;
+    }
+    __syncthreads();
+
+    const char *a_lane = tile + c16 * F16_STRIDE + 32 * kq;             // octet 4 g + kq of row c16 (+ tile offset)
+
+    // ---- phase B: layer 2 (128 -> 128), wave w owns channel tiles 2w, 2w+1 ---------------------------
+    {
+        dclr_f32x4 acc[T][2], acc2[T][2];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { acc[t][u] = 0.f; acc2[t][u] = 0.f; }
+        const float4 *wh = w2p + (size_t)(2 * wave) * F16_KG * 64 + lane;
+        flow16_panel<T, true>(acc, acc2, a_lane, wh, wh + (size_t)(F16_C / 16) * F16_KG * 64, F16_KG * 64);
+        __syncthreads();                                   // every wave has consumed the layer-1 rows
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ch = (2 * wave + u) * 16 + 4 * kq;   // registers i = channels ch + i of neighbour row c16
+            const float4 bv = *reinterpret_cast<const float4 *>(b2 + ch);
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                dclr_h4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaxf(fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]) + bb[i], 0.f);
+                    _Float16 a, b;
+                    dclr_split(v, a, b);
+                    hi[i] = a; lo[i] = b;
+                }
+                char *dst = tile + (t * 16 + c16) * F16_STRIDE + 32 * (ch >> 3) + 2 * (ch & 7);
+                *reinterpret_cast<dclr_h4 *>(dst) = hi;
+                *reinterpret_cast<dclr_h4 *>(dst + 16) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: layer 3 (128 -> 256) + radius mask + max over neighbours; wave w owns channel tiles
+    //      4w .. 4w+3, two at a time ------------------------------------------------------------------
+    {
+        const uint32_t vb = vbits[kq];                     // lane-quarter kq holds template point kq
+        const size_t gp = g0 + kq;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            dclr_f32x4 acc[T][2], acc2[T][2];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { acc[t][u] = 0.f; acc2[t][u] = 0.f; }
+            const int tile0 = 4 * wave + 2 * half;
+            const float4 *wh = w3p + (size_t)tile0 * F16_KG * 64 + lane;
+            flow16_panel<T, false>(acc, acc2, a_lane, wh, wh + (size_t)(F16_OUT / 16) * F16_KG * 64, F16_KG * 64);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = (tile0 + u) * 16 + c16;
+                const float bv = b3[col];
+                float mx = 0.f;                            // ReLU output floor; masked rows contribute 0
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]) + bv;   // neighbour 4t + i
+                        mx = ((vb >> (4 * t + i)) & 1u) ? fmaxf(mx, v) : mx;
+                    }
+                if (gp < total) e_rows[gp * DCLR_E_STRIDE + col] = mx;
+            }
+        }
+    }
+    // template xyz + zero padding (columns 256..263): 4 points x 8 columns = the first 32 threads
+    if (tid < 32) {
+        const size_t gp = g0 + (tid >> 3);
+        const int c = tid & 7;
+        if (gp < total) e_rows[gp * DCLR_E_STRIDE + F16_OUT + c] = c < 3 ? f_rows[gp * DCLR_F_STRIDE + 64 + c] : 0.f;
+    }
+}
+
+template <int T>
+void flow16_launch(int pairs, int npoint, int k, float radius, const float *f_rows, const int32_t *knn_idx,
+                   const float *pt, const float *ps, const float *w1a, const float *b1, const void *w2p,
+                   const float *b2, const void *w3p, const float *b3, float *e_rows, hipStream_t stream) {
+    const size_t total = (size_t)pairs * npoint;
+    hipLaunchKernelGGL((flow16_kernel<T>), dim3((unsigned)((total + F16_G - 1) / F16_G)), dim3(256), 0, stream, pairs,
+                       npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, reinterpret_cast<const float4 *>(w2p), b2,
+                       reinterpret_cast<const float4 *>(w3p), b3, e_rows);
+}
+
+}  // namespace
+
+extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, const float *f_rows,
+                                             const int32_t *knn_idx, const float *pt, const float *ps,
+                                             const float *w1a, const float *b1, const void *w2p, const float *b2,
+                                             const void *w3p, const float *b3, float *e_rows, dclr_stream_t stream) {
+    DCLR_REQUIRE(pairs > 0 && npoint > 0 && f_rows && knn_idx && pt && ps && w1a && b1 && w2p && b2 && w3p &&
+                 b3 && e_rows);
+    if (k < 1 || k > 32) return DCLR_E_UNSUPPORTED;
+    DCLR_REQUIRE(((uintptr_t)w2p & 15) == 0 && ((uintptr_t)w3p & 15) == 0 && ((uintptr_t)pt & 7) == 0 &&
+                 ((uintptr_t)ps & 7) == 0 && ((uintptr_t)b2 & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+#define DCLR_FLOW16_CASE(T) case T: flow16_launch<T>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
+    switch ((k + 3) / 4) {
+        DCLR_FLOW16_CASE(1); DCLR_FLOW16_CASE(2); DCLR_FLOW16_CASE(3); DCLR_FLOW16_CASE(4);
+        DCLR_FLOW16_CASE(5); DCLR_FLOW16_CASE(6); DCLR_FLOW16_CASE(7); DCLR_FLOW16_CASE(8);
+        default: return DCLR_E_UNSUPPORTED;
+    }
+#undef DCLR_FLOW16_CASE
+    return dclr_launch_status();
+}

@@ -1,0 +1,58 @@
+// Split-fp16 MFMA building blocks (gfx950): fp32-accurate products at the fp16 matrix rate.
+//
+// Every fp32 operand x is carried as two halves  hi = f16(x),  lo = f16((x - hi) * 2^11)  and a product
+// is evaluated as  a*b ~= a_hi*b_hi + 2^-11 * (a_hi*b_lo + a_lo*b_hi)  (the lo*lo term, 2^-22 relative,
+// is dropped). hi carries 11 significant bits and the scaled lo the next 11, so the pair holds x to
+// ~2^-22; the three f16 products are exact in the f32 accumulator. Measured on MI355X against fp64
+// (scratch/mfma16_probe.hip, K = 512, all-positive data = worst case for accumulation bias): relative
+// rms error 1.2e-7 for this scheme vs 3.0e-7 for the chained v_mfma_f32_32x32x2_f32 it replaces, i.e.
+// the result is at least as close to the exact product as the fp32 matrix pipe's.
+// Rate: v_mfma_f32_32x32x16_f16 / 16x16x32_f16 retire 16x the MACs per cycle of the f32 forms; at
+// three instructions per product the contraction runs at 16/3 = 5.3x the fp32 matrix peak.
+// Range: |x| must stay below 65504 (f16 max); larger magnitudes saturate (dclr_split clamps).
+//
+// Two accumulators per tile: `acc` takes hi*hi, `acc2` takes both cross terms at scale 2^11;
+// result = acc + acc2 * 2^-11.
+//
+// Fragment layout (both instruction shapes): a lane holds 8 consecutive k of one row/column,
+//   32x32x16: index = lane & 31, k = 16 g + 8 (lane >> 5) + q
+//   16x16x32: index = lane & 15, k = 32 g + 8 (lane >> 4) + q
+// so in memory one "k-octet" is 16 bytes of hi followed by 16 bytes of lo:
+//   activations (LDS)  row r, octet o:  byte r * stride + 32 o  (hi)  /  + 16  (lo)
+//   weights (global)   plane hi then plane lo, each  [(tile * KG + g) * 64 + lane]  16-byte fragments
+// The A and B operand maps are symmetric, so the same fragments serve W*X^T (output lane = point,
+// registers = 4 consecutive channels: what the next layer's octets need) and X*W^T (output lane =
+// channel, registers = points: what a max over points needs).
+#pragma once
+#include "mma.h"
+
+typedef _Float16 dclr_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dclr_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dclr_h2 __attribute__((ext_vector_type(2)));
+
+constexpr float DCLR_SPLIT_SCALE = 2048.f;
+constexpr float DCLR_SPLIT_INV = 1.f / 2048.f;
+constexpr float DCLR_F16_MAX = 65504.f;
+
+__device__ __forceinline__ void dclr_split(float v, _Float16 &hi, _Float16 &lo) {
+    const float c = fminf(fmaxf(v, -DCLR_F16_MAX), DCLR_F16_MAX);
+    hi = (_Float16)c;
+    lo = (_Float16)fminf(fmaxf((v - (float)hi) * DCLR_SPLIT_SCALE, -DCLR_F16_MAX), DCLR_F16_MAX);
+}
+
+// LDS row stride in BYTES for kp values per row (kp % 16 == 0): 4 kp + 16, i.e. (stride / 16) odd, so the
+// 16 or 32 rows addressed by one ds_read_b128 fall into distinct 16-byte bank groups.
+__host__ __device__ constexpr int dclr_split_stride(int kp) { return 4 * kp + 16; }
+
+__device__ __forceinline__ dclr_h8 dclr_lds_h8(const char *p) { return *reinterpret_cast<const dclr_h8 *>(p); }
+__device__ __forceinline__ dclr_h8 dclr_frag_h8(const float4 *p) {
+    const float4 v = *p;
+    return __builtin_bit_cast(dclr_h8, v);
+}
+
+__device__ __forceinline__ dclr_f32x16 dclr_mfma32(dclr_h8 a, dclr_h8 b, dclr_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ dclr_f32x4 dclr_mfma16(dclr_h8 a, dclr_h8 b, dclr_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}

@@ -37,6 +37,9 @@ SIGNATURES = {
     'dclr_knn_rows': [_i, _i, _i, _p, _p, _p],
     'dclr_flow_embedding_fused': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_fc': [_i, _i, _i, _p, _p, _p, _i, _p, _p],
+    'dclr_pack_weight_f16': [_i, _i, _p, _p, _i, _i, _p, _p],
+    'dclr_head_conv_fused_f16': [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
+    'dclr_flow_embedding_fused_f16': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_prepare_cloud_blocks': [_i, _i, _i],
     'dclr_prepare_cloud': [_i, _i, _p, _i, _i, _f, _f, _i, _p, _p, _p, _p],
 }

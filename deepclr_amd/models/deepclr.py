@@ -134,6 +134,7 @@ class MotionEmbeddingBase(nn.Module):
                 'wt': ops.pack_weight(w_t.contiguous(), FEAT, kmap), 'ws': ops.pack_weight(w_s.contiguous(), FEAT, kmap),
                 'w2p': ops.pack_weight(w2, 128, tile16=True), 'b2': b2.detach().contiguous(),
                 'w3p': ops.pack_weight(w3, 128, tile16=True), 'b3': b3.detach().contiguous(),
+                'w2h': ops.pack_weight_f16(w2, 128, 16), 'w3h': ops.pack_weight_f16(w3, 128, 16),
             }
         return self._cache.get(list(self.parameters()), build)
 
@@ -144,6 +145,9 @@ class MotionEmbeddingBase(nn.Module):
         pt = ops.linear(f_rows[:half], p['wt'], None, 128, FEAT, relu=False)
         ps = ops.linear(f_rows[half:], p['ws'], None, 128, FEAT, relu=False)
         knn_idx = ops.knn_rows(f_rows, pairs, npoint, self._k)
+        if ops.PRECISION == 'f16x2':
+            return ops.flow_embedding_fused_f16(f_rows, knn_idx, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'],
+                                                p['w3h'], p['b3'], self._radius)
         return ops.flow_embedding_fused(f_rows, knn_idx, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'],
                                         p['w3p'], p['b3'], self._radius)
 
@@ -194,6 +198,7 @@ class OutputSimple(DeepCLRModule):
                 self.output.bias.copy_(torch.tensor(label_type.bias, dtype=torch.float32))
         self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
         self._cache = PackedCache()
+        self._cache16 = PackedCache()
 
     def output_dim(self) -> int:
         return self._label_type.dim
@@ -216,18 +221,41 @@ class OutputSimple(DeepCLRModule):
             return layers
         return self._cache.get(list(self.conv.parameters()), build)
 
+    def _packed_f16(self):
+        def build():
+            layers = []
+            for i, (w, b) in enumerate(self.conv.affine_params()):
+                n, k_in = w.shape[0], w.shape[1]
+                if i == 0:      # rows E: [feat | xyz | pad] -> 272 columns (k-steps of 16), the rest zero weights
+                    kp = (ops.E_STRIDE + 15) // 16 * 16
+                    kmap = torch.full((kp,), -1, dtype=torch.int32, device=w.device)
+                    kmap[:256] = torch.arange(3, 259, dtype=torch.int32, device=w.device)
+                    kmap[256:259] = torch.arange(0, 3, dtype=torch.int32, device=w.device)
+                    wp = ops.pack_weight_f16(w, kp, 32, kmap)
+                else:
+                    kp = (k_in + 15) // 16 * 16
+                    wp = ops.pack_weight_f16(w, kp, 32)
+                layers.append((wp, b.detach().contiguous(), n, kp))
+            return layers
+        return self._cache16.get(list(self.conv.parameters()), build)
+
     def _fusable(self, layers, rows: int, pairs: int) -> bool:
         """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512. Its grid is
-        rows / 32 workgroups, one per CU: below half the chip (single pairs, the reference's own batch size) the
-        per-layer kernels, whose grids also split the output columns, finish sooner (84 vs 142 us at one pair)."""
-        return (rows >= 4096 and rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
+        rows / 32 workgroups, one per CU. On the f32 matrix path, below half the chip (single pairs, the reference's
+        own batch size) the per-layer kernels, whose grids also split the output columns, finish sooner (84 vs
+        142 us at one pair); the split-fp16 chain (65 us) is used at every batch size, which also keeps the
+        result of a pair independent of the batch it travels in."""
+        return ((rows >= 4096 or ops.PRECISION == 'f16x2') and rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
                 and all(n % 32 == 0 for _, _, n, _ in layers) and all(kp <= 512 for _, _, _, kp in layers)
                 and all(n <= 512 for _, _, n, _ in layers[:-1]))
 
     def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         layers = self._packed()
         if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
-            g = ops.head_conv_fused(e_rows, layers, pairs)                   # conv chain + max over points
+            if ops.PRECISION == 'f16x2':
+                g = ops.head_conv_fused_f16(e_rows, ops.E_STRIDE, self._packed_f16(), pairs)
+            else:
+                g = ops.head_conv_fused(e_rows, layers, pairs)               # conv chain + max over points
             g = self.linear(g)
             return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
         h = e_rows

@@ -8,6 +8,7 @@ Level 1 mirrors, name for name and argument for argument, what
 kernels the model forward uses. Everything runs on the current torch stream.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -20,6 +21,11 @@ E_STRIDE = 264
 # Optional launch timer (bench.py): an object with begin(name) -> token and end(token), called on the
 # stream the kernel is enqueued on. None in normal operation.
 TIMER = None
+
+# Matrix path of the fused flow-embedding and pose-head kernels: 'f16x2' = f32 operands split into f16 hi/lo
+# halves on the f16 matrix instructions (f32-accurate, csrc/mma16f.h), 'f32' = the f32 matrix instructions.
+PRECISION = os.environ.get('DCLR_PRECISION', 'f16x2')
+
 
 
 def _call(name: str, what: str, *args) -> None:
@@ -250,6 +256,46 @@ def head_conv_fused(x: torch.Tensor, layers, groups: int) -> torch.Tensor:
           ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p), x.data_ptr(), ldx, out.data_ptr(),
           m // groups, lib.stream_ptr())
     return out
+
+
+def pack_weight_f16(w: torch.Tensor, kp: int, width: int, kmap: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row-major (n_out, k_in) -> split-fp16 fragments (hi plane | lo plane) for `width`-column MFMA tiles."""
+    w = lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w')
+    n_out, k_in = w.shape
+    np_ = (n_out + width - 1) // width * width
+    packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)          # 2 planes of np*kp halves
+    if kmap is not None:
+        assert kmap.dtype == torch.int32 and kmap.numel() == kp and kmap.is_cuda
+    _call('dclr_pack_weight_f16', 'pack_weight_f16', n_out, k_in, w.data_ptr(), lib.ptr(kmap), kp, width,
+          packed.data_ptr(), lib.stream_ptr())
+    return packed
+
+
+def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torch.Tensor:
+    """head_conv_fused on the split-fp16 matrix path; layers = [(w_packed_f16, bias, n, kp), ...], kp % 16 == 0."""
+    x = lib.dev_f32(x, 'x')
+    m, ldx = x.shape
+    nl = len(layers)
+    k_h = (ctypes.c_int * nl)(*[int(l[3]) for l in layers])
+    n_h = (ctypes.c_int * nl)(*[int(l[2]) for l in layers])
+    w_h = (ctypes.c_void_p * nl)(*[l[0].data_ptr() for l in layers])
+    b_h = (ctypes.c_void_p * nl)(*[l[1].data_ptr() for l in layers])
+    out = torch.zeros(groups, layers[-1][2], dtype=torch.float32, device=x.device)
+    _call('dclr_head_conv_fused_f16', 'head_conv_fused', m, nl, int(k_in), ctypes.cast(k_h, ctypes.c_void_p),
+          ctypes.cast(n_h, ctypes.c_void_p), ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p),
+          x.data_ptr(), ldx, out.data_ptr(), m // groups, lib.stream_ptr())
+    return out
+
+
+def flow_embedding_fused_f16(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.Tensor, ps: torch.Tensor,
+                             w1a: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+                             w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
+    pairs, npoint, k = knn_idx.shape
+    e = torch.empty(pairs * npoint, E_STRIDE, dtype=torch.float32, device=f_rows.device)
+    _call('dclr_flow_embedding_fused_f16', 'flow_embedding', pairs, npoint, k, float(radius), f_rows.data_ptr(),
+          knn_idx.data_ptr(), pt.data_ptr(), ps.data_ptr(), w1a.data_ptr(), b1.data_ptr(), w2p.data_ptr(),
+          b2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), e.data_ptr(), lib.stream_ptr())
+    return e
 
 
 def knn_rows(f_rows: torch.Tensor, pairs: int, npoint: int, k: int) -> torch.Tensor:

@@ -185,6 +185,26 @@ int dclr_flow_embedding_fused(int pairs, int npoint, int k, float radius, const 
 int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act, float *y,
             dclr_stream_t stream);
 
+/* ---- split-fp16 matrix path (deepclr_amd/csrc/mma16f.h) ------------------------------------------------
+ * The same operators as dclr_head_conv_fused / dclr_flow_embedding_fused with every f32 operand carried as
+ * f16 hi + f16 lo * 2^-11 and each product evaluated as hi*hi + 2^-11 (hi*lo + lo*hi) on the f16 matrix
+ * instructions with f32 accumulation: f32-accurate results (measured closer to fp64 than the f32 matrix
+ * path) at 16/3 of its rate. Operands must stay below 65504 in magnitude.
+ * dclr_pack_weight_f16: w (n_out, k_in) row-major -> hi plane | lo plane (np * kp halves each), fragment
+ *   order for `width`-column tiles (32: head, kp % 16 == 0; 16: flow embedding, kp % 32 == 0); kmap as in
+ *   dclr_pack_weight. packed: 4 * np * kp bytes, 16-byte aligned.
+ * dclr_head_conv_fused_f16: x rows hold k_in valid f32 columns (k_in % 8 == 0, k_in <= k[0]); k[l] % 16 == 0.
+ * dclr_flow_embedding_fused_f16: w2p / w3p packed with width 16, kp 128. */
+int dclr_pack_weight_f16(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int width, void *packed,
+                         dclr_stream_t stream);
+int dclr_head_conv_fused_f16(int m, int n_layers, int k_in, const int *k_host, const int *n_host,
+                             const void *const *w_packed_host, const float *const *bias_host, const float *x,
+                             int ldx, float *colmax, int rows_per_group, dclr_stream_t stream);
+int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, const float *f_rows,
+                                  const int32_t *knn_idx, const float *pt, const float *ps, const float *w1a,
+                                  const float *b1, const void *w2p, const float *b2, const void *w3p,
+                                  const float *b3, float *e_rows, dclr_stream_t stream);
+
 /* ---- scan preparation (reference: CPU transforms run per sample before the model) -----------------------
  * One order-preserving pass over a raw scan raw (n_raw, c_raw): keep rows start, start+nth, ...
  * (SystematicErasing, /root/reference/deepclr/data/transforms/transforms.py:244-268), of those the rows with

@@ -257,8 +257,9 @@ def test_linear_kernel_against_torch():
 
 
 def test_fused_head_chain_equals_layer_by_layer_kernels():
-    """Batches of >= 4 pairs run the five head layers in one launch, smaller ones layer by layer: same k order in
-    both, so the results must be identical, not just close."""
+    """Batches of >= 4 pairs run the five head layers in one launch, smaller ones layer by layer. On the f32 matrix
+    instructions both use the same k order: identical results. The split-fp16 chain (default) must agree with the
+    float64 product at least as well as those do."""
     cfg = synthetic.model_cfg('kitti')
     model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=7))
     head = model._merge_layers[1]
@@ -266,8 +267,13 @@ def test_fused_head_chain_equals_layer_by_layer_kernels():
     rows, pairs = 4096, 4
     e = torch.zeros(rows, ops.E_STRIDE, device=DEV)
     e[:, :259] = torch.from_numpy(np.random.default_rng(3).normal(size=(rows, 259)).astype(np.float32)).to(DEV)
-    assert head._fusable(layers, rows, pairs) and not head._fusable(layers, rows // 2, pairs // 2)
+    saved, ops.PRECISION = ops.PRECISION, 'f32'
+    try:
+        assert head._fusable(layers, rows, pairs) and not head._fusable(layers, rows // 2, pairs // 2)
+    finally:
+        ops.PRECISION = saved
     fused = ops.head_conv_fused(e, layers, pairs)
+    split = ops.head_conv_fused_f16(e, ops.E_STRIDE, head._packed_f16(), pairs)   # f16 hi/lo operands, f32-accurate
     h = e
     for wp, b, n, kp in layers[:-1]:
         h = ops.linear(h, wp, b, n, kp, relu=True, ldy=(n + 7) // 8 * 8)
@@ -278,7 +284,11 @@ def test_fused_head_chain_equals_layer_by_layer_kernels():
     want = torch.cat((want[:, 256:259], want[:, :256]), dim=1)                 # reference column order [xyz | feat]
     for w, bias in head.conv.affine_params():
         want = torch.relu(want @ w.detach().double().cpu().reshape(w.shape[0], -1).t() + bias.detach().double().cpu())
-    _close(fused, want.view(pairs, rows // pairs, -1).max(dim=1).values.float())
+    want = want.view(pairs, rows // pairs, -1).max(dim=1).values
+    _close(fused, want.float())
+    _close(split, want.float())
+    err32, err16 = (fused.double().cpu() - want).abs().max().item(), (split.double().cpu() - want).abs().max().item()
+    assert err16 <= 2 * err32 + 1e-7, (err16, err32)        # no less accurate than the f32 matrix instructions
 
 
 def test_full_size_kitti_batch_properties_and_oracle_pair():
@@ -299,8 +309,9 @@ def test_full_size_kitti_batch_properties_and_oracle_pair():
     assert (reach[:, 1:] <= reach[:, :-1] + 1e-9).all()
     with torch.no_grad():
         y, _, _ = model(x.clone())
+        y_half, _, _ = model(x[[0, 1, 2, 3, 8, 9, 10, 11]].clone())
         y_single, _, _ = model(x[[0, 8]].clone())
-    assert torch.equal(y[0], y_single[0])                                     # pairs are independent
+    assert torch.equal(y[:4], y_half) and torch.equal(y[:1], y_single)        # pairs are independent
     y_o = orc(torch.from_numpy(x_np[[0, 8]]))
     _close(y[:1], y_o)
     assert pose_delta(_mats(y[:1]), np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])) < 1e-4
@@ -358,3 +369,45 @@ def test_sequence_mode_computes_each_frame_once_and_matches_pairwise_calls():
     assert torch.equal(piped, want)
     y_o = orc(torch.stack((frames[2], frames[3])).cpu())                        # pair (frame 2 -> frame 3)
     _close(want[2:3], y_o)
+
+
+@pytest.mark.parametrize('k,radius', [(20, 10.0), (7, 0.6), (30, 0.2)])
+def test_flow_embedding_split_fp16_against_f32_path_and_float64(k, radius):
+    """Flow-embedding kernel on both matrix paths: same neighbours, same mask; values against a float64 product."""
+    cfg = synthetic.model_cfg('kitti')
+    cfg['params']['merge']['params']['k'] = k
+    cfg['params']['merge']['params']['radius'] = radius
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=9))
+    x = torch.from_numpy(synthetic.make_batch('kitti', 2, 4096, first_pair=3)).to(DEV)
+    me = model._merge_layers[0]._embedding
+    saved = ops.PRECISION
+    try:
+        with torch.no_grad():
+            f_rows = model.cloud_feature_rows(x)
+            ops.PRECISION = 'f32'
+            e32 = me.forward_rows(f_rows, 2, model.npoint)
+            ops.PRECISION = 'f16x2'
+            e16 = me.forward_rows(f_rows, 2, model.npoint)
+    finally:
+        ops.PRECISION = saved
+    assert torch.equal(e32[:, 256:], e16[:, 256:])                            # xyz + padding columns: copies
+    assert torch.equal(e32 == 0, e16 == 0) or (e32 - e16).abs().max() < 1e-5   # same radius mask
+    # float64 restatement of deepclr.py:201-231 on the kernel's own neighbour lists
+    (w1, b1), (w2, b2), (w3, b3) = [(w.detach().double().reshape(w.shape[0], -1), b.detach().double())
+                                    for w, b in me._conv.affine_params()]
+    n = model.npoint
+    idx = ops.knn_rows(f_rows, 2, n, k).long()
+    f = f_rows.double()
+    tmpl, src = f[:2 * n].view(2, n, -1), f[2 * n:].view(2, n, -1)
+    nb = torch.gather(src.unsqueeze(1).expand(-1, n, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, f.shape[1]))
+    diff = nb[..., 64:67] - tmpl[:, :, None, 64:67]
+    merged = torch.cat((diff, tmpl[:, :, None, :64].expand(-1, -1, k, -1), nb[..., :64]), dim=-1)
+    h = torch.relu(merged @ w1.t() + b1)
+    h = torch.relu(h @ w2.t() + b2)
+    h = torch.relu(h @ w3.t() + b3)
+    h = torch.where((diff.norm(dim=-1, keepdim=True) >= radius), torch.zeros_like(h), h).max(dim=2).values
+    want = h.view(2 * n, 256)
+    err32 = (e32[:, :256].double() - want).abs().max().item()
+    err16 = (e16[:, :256].double() - want).abs().max().item()
+    _close(e16[:, :256], want.float().cpu())
+    assert err16 <= 2 * err32 + 1e-7, (err16, err32)
