@@ -34,7 +34,8 @@ namespace {
 constexpr int SA_WAVES = 4;
 constexpr int SA_CPW = 8;                       // centroids per wave
 constexpr int SA_TILE = 512;                    // points per LDS tile
-constexpr int SA_RING = 512;                    // ring capacity (>= 63 + 4 * 64 staged between drain checks), power of two
+constexpr int SA_RING = 512;                    // ring capacity: < 64 left over + one centroid's neighbours (fast path) or
+                                                // + 4 slices staged between drain checks (sweep); power of two
 constexpr int SA_MAX_SCALES = 2;
 constexpr int SA_H1 = 16, SA_H2 = 16, SA_OUT = 32;
 constexpr int SA_OSTRIDE = SA_OUT + 1;          // output row: 32 channels + centroid tag, odd stride
@@ -251,10 +252,14 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
             const float cx = sa_cxyz[wave][c][0], cy = sa_cxyz[wave][c][1], cz = sa_cxyz[wave][c][2];
             const float lbv = sa_box_lower_bound(blx, bly, blz, bhx, bhy, bhz, cx, cy, cz);
             const uint64_t gmask = __ballot(have && lbv < prm.radius2_max);
-            // pass 1: count the neighbours of both scales
+            // One pass: neighbours are staged for the MLP as they are found (any order) and counted. If a cap
+            // turns out to be exceeded -- index order then decides which nsample neighbours count -- or the
+            // ring would overflow, the centroid's entries are taken back (nothing of it has been drained:
+            // drains happen between centroids only) and it is left to the in-order sweep.
+            // Two candidate groups (<= 8 slices of 64 points) per step, all loads issued before the first
+            // use: one slice at a time the scan is a chain of ~250 dependent L2 round trips per wave.
             int n1[SA_MAX_SCALES] = {0, 0};
-            // two candidate groups (<= 8 slices of 64 points) per step, all loads issued before the first
-            // use: one slice at a time the scan is a chain of ~250 dependent L2 round trips per wave
+            const int q0[SA_MAX_SCALES] = {qn[0], qn[1]};
             auto load_pair = [&](uint64_t &m, float4 (&q)[8], int &nq) {
                 const int ga = __builtin_ctzll(m);
                 m &= m - 1;
@@ -271,25 +276,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 }
                 nq = two ? 8 : 4;
             };
-            for (uint64_t m = gmask; m != 0;) {
-                float4 q[8];
-                int nq;
-                load_pair(m, q, nq);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool valid = (u & 3) < slices && u < nq && __float_as_uint(q[u].w) != 0xFFFFFFFFu;
-                    const float d2 = dclr_sqdist(cx, cy, cz, q[u].x, q[u].y, q[u].z);
-#pragma unroll
-                    for (int s = 0; s < SA_MAX_SCALES; ++s)
-                        if (s < prm.n_scales) n1[s] += __builtin_popcountll(__ballot(valid && d2 < prm.radius2[s]));
-                }
-            }
-            if (n1[0] > prm.nsample[0] || (prm.n_scales > 1 && n1[1] > prm.nsample[1])) {
-                need_sweep = true;                         // cap reached: index order matters -> in-order sweep
-                continue;
-            }
-            // pass 2: stage the neighbours (any order) for the MLP
-            for (uint64_t m = gmask; m != 0;) {
+            bool over = false;
+            for (uint64_t m = gmask; m != 0 && !over;) {
                 float4 q[8];
                 int nq;
                 load_pair(m, q, nq);
@@ -303,16 +291,27 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                         const bool hit = valid && d2 < prm.radius2[s];
                         const uint64_t mask = __ballot(hit);
                         if (mask != 0) {
-                            const int pre = (int)dclr_lanemask_lt_popc(mask);
-                            if (hit)
-                                sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] =
-                                    ((uint32_t)c << 16) | (__float_as_uint(q[u].w) & 0xFFFFu);
-                            qn[s] += __builtin_popcountll(mask);
+                            const int add = __builtin_popcountll(mask);
+                            n1[s] += add;
+                            if (qn[s] + 64 > SA_RING) {        // a slice adds <= 64 entries: never onto live ones
+                                over = true;                   // crowded centroid (> ~450 neighbours): in-order sweep
+                            } else {
+                                const int pre = (int)dclr_lanemask_lt_popc(mask);
+                                if (hit)
+                                    sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] =
+                                        ((uint32_t)c << 16) | (__float_as_uint(q[u].w) & 0xFFFFu);
+                                qn[s] += add;
+                            }
                         }
                     }
-                    if ((u & 3) == 3 && (qn[0] >= 64 || qn[1] >= 64)) drain_all(false);   // <= 256 staged per check
                 }
             }
+            if (over || n1[0] > prm.nsample[0] || (prm.n_scales > 1 && n1[1] > prm.nsample[1])) {
+                qn[0] = q0[0]; qn[1] = q0[1];
+                need_sweep = true;
+                continue;
+            }
+            if (qn[0] >= 64 || qn[1] >= 64) drain_all(false);
             done |= 1u << c;
             if (lane == 0) { sa_tot[wave][c][0] = n1[0]; sa_tot[wave][c][1] = n1[1]; }
         }
