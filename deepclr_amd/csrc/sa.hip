@@ -27,7 +27,7 @@
 // Slots that would only repeat the first hit are skipped: max() over a multiset equals max() over
 // its support, so the result is identical. A centroid with no hit reproduces the published
 // behaviour (zero-filled index row => every slot is point 0).
-#include "common.h"
+#include "mma.h"
 
 namespace {
 
@@ -63,38 +63,6 @@ __device__ __forceinline__ float4 sa_load_point(const float *__restrict__ cloud,
 
 constexpr int SA_MLP_FLOATS = SA_H1 * 4 + SA_H1 + SA_H2 * SA_H1 + SA_H2 + SA_OUT * SA_H2 + SA_OUT;   // 896 at c = 4
 
-// 3-layer shared MLP on one neighbour. The weights sit in LDS (staged once per workgroup) and are read
-// with wave-uniform addresses (broadcast): as scalar loads they arrived ~16 at a time through a
-// serial s_load chain and one 64-entry pass took ~34k cycles.
-template <int C>
-__device__ __forceinline__ void sa_mlp(const float *w, const float (&in)[4], float (&out)[SA_OUT]) {
-    const float *w1 = w;
-    const float *b1 = w1 + SA_H1 * C, *w2 = b1 + SA_H1, *b2 = w2 + SA_H2 * SA_H1;
-    const float *w3 = b2 + SA_H2, *b3 = w3 + SA_OUT * SA_H2;
-    float h1[SA_H1], h2[SA_H2];
-#pragma unroll
-    for (int o = 0; o < SA_H1; ++o) {
-        float a = b1[o];
-#pragma unroll
-        for (int i = 0; i < C; ++i) a = fmaf(w1[o * C + i], in[i], a);
-        h1[o] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < SA_H2; ++o) {
-        float a = b2[o];
-#pragma unroll
-        for (int i = 0; i < SA_H1; ++i) a = fmaf(w2[o * SA_H1 + i], h1[i], a);
-        h2[o] = fmaxf(a, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < SA_OUT; ++o) {
-        float a = b3[o];
-#pragma unroll
-        for (int i = 0; i < SA_H2; ++i) a = fmaf(w3[o * SA_H2 + i], h2[i], a);
-        out[o] = fmaxf(a, 0.f);
-    }
-}
-
 // Workgroup-shared state. Namespace scope so that the (deliberately not inlined) drain routine can
 // address it; both template instances of the kernel use the same layout.
 __shared__ float4 sa_tile[2][SA_TILE];
@@ -107,50 +75,72 @@ __shared__ uint32_t sa_acc[SA_WAVES][SA_MAX_SCALES][SA_CPW][SA_OUT];
 __shared__ int sa_tot[SA_WAVES][SA_CPW][SA_MAX_SCALES];
 __shared__ __attribute__((aligned(16))) float sa_w[SA_MAX_SCALES][SA_MLP_FLOATS];       // true neighbour counts of centroids done on the fast path
 
-// One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`, lane = entry; the results
-// are folded into sa_acc. Kept out of line on purpose: inlined into the sweep loop its ~100 scalar
-// weight registers push the loop-carried scalars (centroids, counters) into spill lanes.
+// One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`; the results are folded into
+// sa_acc. Kept out of line on purpose (one copy, called from three places).
+//
+// The three layers run on v_mfma_f32_16x16x4_f32 as W * H^T with the entries as COLUMNS (four tiles of 16
+// entries): the accumulator of lane (entry e = lane & 15, quarter kq = lane >> 4) holds channels
+// 4 kq .. 4 kq + 3 of entry e, which is exactly the B operand the next layer needs when step j of its K loop
+// is given k = 4 kq + j -- so the activations never leave the registers between layers; only the weight
+// fragments (A operand, lane (m, kq) holds W[m][4 kq .. 4 kq + 3]) are laid out for that k order.
+// 52 MFMAs per pass; the scalar version (lane = entry, 832 FMAs with LDS-broadcast weights) took ~20k
+// cycles per pass and dominated the kernel wherever neighbourhoods are dense.
 template <int C>
 __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int head, int take) {
     cloud = dclr_uniform(cloud);
     wave = dclr_uniform(wave); s = dclr_uniform(s); head = dclr_uniform(head); take = dclr_uniform(take);
-    const int lane = dclr_lane();
-    const bool valid = lane < take;
-    const uint32_t e = valid ? sa_ring[wave][s][(head + lane) & (SA_RING - 1)] : 0u;
-    const int c = (int)(e >> 16), k = (int)(e & 0xFFFFu);
-    const float4 p = sa_load_point<C>(cloud, k);
-    float in[4] = {p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w};
-    float h[SA_OUT];
-    sa_mlp<C>(&sa_w[s][0], in, h);
-    // transpose through LDS in two halves of 32 entries (rows of one wave only: the wave's own LDS
-    // writes are ordered before its reads). Lane = (row parity, channel) walks the rows; entries of a
-    // centroid mostly form runs, so the running maximum is committed (LDS atomic max) only when the
-    // centroid changes.
-    const int ch = lane & 31;
-    uint32_t *acc = &sa_acc[wave][s][0][ch];
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int rows = take - 32 * half < 32 ? take - 32 * half : 32;     // wave-uniform
-        if (rows <= 0) break;
-        if ((lane >> 5) == half) {
-            float *orow = &sa_obuf[wave][(lane & 31) * SA_OSTRIDE];
+    const int lane = dclr_lane(), e16 = lane & 15, kq = lane >> 4;
+    // stage the inputs (lane = entry): relative position + feature, and the centroid slot (-1: no entry)
+    float *stg = sa_obuf[wave];
+    int *tag = reinterpret_cast<int *>(stg + 256);
+    {
+        const bool valid = lane < take;
+        const uint32_t e = valid ? sa_ring[wave][s][(head + lane) & (SA_RING - 1)] : 0u;
+        const int c = (int)(e >> 16), k = (int)(e & 0xFFFFu);
+        const float4 p = sa_load_point<C>(cloud, k);
+        *reinterpret_cast<float4 *>(stg + 4 * lane) =
+            make_float4(p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w);
+        tag[lane] = valid ? c : -1;
+    }
+    const float *w1 = &sa_w[s][0];
+    const float *b1 = w1 + SA_H1 * C, *w2 = b1 + SA_H1, *b2 = w2 + SA_H2 * SA_H1;
+    const float *w3 = b2 + SA_H2, *b3 = w3 + SA_OUT * SA_H2;
+    const float a1 = kq < C ? w1[e16 * C + kq] : 0.f;                        // W1[m][k = kq]
+    float a2[4], a3[2][4], c1[4], c2[4], c3[2][4];
 #pragma unroll
-            for (int o = 0; o < SA_OUT; ++o) orow[o] = h[o];
-            orow[SA_OUT] = __int_as_float(c);
+    for (int j = 0; j < 4; ++j) {
+        a2[j] = w2[e16 * SA_H1 + 4 * kq + j];
+        a3[0][j] = w3[e16 * SA_H2 + 4 * kq + j];
+        a3[1][j] = w3[(16 + e16) * SA_H2 + 4 * kq + j];
+        c1[j] = b1[4 * kq + j]; c2[j] = b2[4 * kq + j];
+        c3[0][j] = b3[4 * kq + j]; c3[1][j] = b3[16 + 4 * kq + j];
+    }
+    uint32_t *acc = &sa_acc[wave][s][0][0];
+#pragma unroll 1
+    for (int t = 0; 16 * t < take; ++t) {
+        const float x = stg[4 * (16 * t + e16) + kq];                        // input component kq of entry 16 t + e16
+        dclr_f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
+        h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x, h1, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h1[i] = fmaxf(h1[i] + c1[i], 0.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], h1[j], h2, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h2[i] = fmaxf(h2[i] + c2[i], 0.f);
+        dclr_f32x4 h3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[0][j], h2[j], h3[0], 0, 0, 0);
+            h3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[1][j], h2[j], h3[1], 0, 0, 0);
         }
-        int cur = -1;
-        float m = 0.f;
-        for (int r = lane >> 5; r < rows; r += 2) {
-            const float v = sa_obuf[wave][r * SA_OSTRIDE + ch];
-            const int rc = __float_as_int(sa_obuf[wave][r * SA_OSTRIDE + SA_OUT]);
-            if (rc != cur) {
-                if (cur >= 0) atomicMax(acc + cur * SA_OUT, __float_as_uint(m));
-                cur = rc;
-                m = 0.f;
-            }
-            m = fmaxf(m, v);
+        const int cen = tag[16 * t + e16];
+        if (cen >= 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    atomicMax(acc + cen * SA_OUT + 16 * u + 4 * kq + i, __float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
         }
-        if (cur >= 0) atomicMax(acc + cur * SA_OUT, __float_as_uint(m));
     }
 }
 
