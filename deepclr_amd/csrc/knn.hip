@@ -62,23 +62,37 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
             // (candidate - query), accumulated x,y,z: the published kernel's order
             d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
         }
+        // Each lane keeps its two nearest unused candidates (m1 <= m2, ties in index order); a round is then one
+        // wave arg-min over m1 plus a pop in the winning lane. Only when a lane has been popped twice -- k picks
+        // spread over 64 lanes: about once per query -- are the pairs rebuilt from the distance registers
+        // (rescanning all CPL registers every round, as a plain selection does, is ~3x the instructions).
+        uint64_t used = 0;                                   // bit c: this lane's candidate c is already output
+        uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+        int c1 = 0, c2 = 0, have = 0;                        // have: how many of (m1, m2) are still valid
 #pragma unroll 1
         for (int s = 0; s < k; ++s) {
-            uint32_t lmin = d[0];
-            int lc = 0;
+            if (__ballot(have == 0) != 0) {                  // wave-uniform
+                m1 = 0xFFFFFFFFu; m2 = 0xFFFFFFFFu; c1 = 0; c2 = 0;
 #pragma unroll
-            for (int c = 1; c < CPL; ++c) {
-                const bool lt = d[c] < lmin;
-                lc = lt ? c : lc;
-                lmin = lt ? d[c] : lmin;
+                for (int c = 0; c < CPL; ++c) {
+                    const uint32_t v = ((used >> c) & 1ull) ? 0xFFFFFFFFu : d[c];
+                    const bool lt1 = v < m1, lt2 = v < m2;
+                    c2 = lt1 ? c1 : (lt2 ? c : c2);
+                    m2 = lt1 ? m1 : (lt2 ? v : m2);
+                    c1 = lt1 ? c : c1;
+                    m1 = lt1 ? v : m1;
+                }
+                have = 2;
             }
-            const uint32_t li = (uint32_t)(lc * 64 + lane);
-            const uint32_t wmin = dclr_wave_min_u32(lmin);
-            const uint32_t widx = dclr_wave_min_u32(lmin == wmin ? li : 0xFFFFFFFFu);
+            const uint32_t li = (uint32_t)(c1 * 64 + lane);
+            const uint32_t wmin = dclr_wave_min_u32(m1);
+            const uint32_t widx = dclr_wave_min_u32(m1 == wmin ? li : 0xFFFFFFFFu);
             if (lane == 0) out(q, s, wmin >= KNN_INF ? -1 : (int)widx);
-            const int wc = (int)(widx >> 6), wl = (int)(widx & 63);
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) d[c] = (lane == wl && c == wc) ? KNN_INF : d[c];
+            if (lane == (int)(widx & 63)) {
+                used |= 1ull << (widx >> 6);
+                m1 = m2; c1 = c2; m2 = 0xFFFFFFFFu;
+                have -= 1;
+            }
         }
     }
 }
