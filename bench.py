@@ -45,6 +45,8 @@ class LaunchTimer:
 
     def __init__(self, sample_every=None):
         self.spans = []
+        self.raw = []
+        self._hip = None
         self.main_stream = torch.cuda.current_stream().cuda_stream
         self.step = 0
         if sample_every is not None:
@@ -67,11 +69,39 @@ class LaunchTimer:
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
 
+    def merge_events(self, rows):
+        """Raw HIP events for the stages of one dclr_merge_forward call (the dense stages are one foreign call;
+        the library records these between its launches, on the launch stream)."""
+        if self.step % self.SAMPLE_EVERY != 0:
+            return None
+        import ctypes
+        from deepclr_amd import lib
+        if self._hip is None:
+            self._hip = ctypes.CDLL('libamdhip64.so')
+        arr = (ctypes.c_void_p * lib.MERGE_EVENTS)()
+        for i in range(lib.MERGE_EVENTS):
+            ev = ctypes.c_void_p()
+            if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
+                return None
+            arr[i] = ev.value
+        names = ['linear[%dx128x64]' % rows] * 2 + ['knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * 4
+        on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
+        self.raw.append((arr, names, on_main))
+        return arr
+
     def summary(self):
         acc = {}
         for name, a, b, on_main in self.spans:
             tot, cnt, _ = acc.get(name, (0.0, 0, on_main))
             acc[name] = (tot + a.elapsed_time(b), cnt + 1, on_main)
+        import ctypes
+        for arr, names, on_main in self.raw:
+            for i, name in enumerate(names):
+                ms = ctypes.c_float()
+                if self._hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(arr[i]), ctypes.c_void_p(arr[i + 1])) != 0:
+                    continue                                  # slot not recorded (fewer fully connected layers)
+                tot, cnt, _ = acc.get(name, (0.0, 0, on_main))
+                acc[name] = (tot + ms.value, cnt + 1, on_main)
         return {k: {'total_ms': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1], 'main_stream': v[2]}
                 for k, v in acc.items()}
 
@@ -135,6 +165,7 @@ def main():
     ap.add_argument('--sequence', action='store_true',
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
+    ap.add_argument('--group', type=int, default=1, help='batches sampled by one launch on a side stream')
     ap.add_argument('--ahead', default='features', choices=['sample', 'features'], help='stages run ahead')
     args = ap.parse_args()
 
@@ -167,10 +198,11 @@ def main():
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
-        runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead)
+        runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
+                                                               group=args.group)
     if runner is not None:
-        for _ in range(args.depth):
-            runner.prefetch(x)
+        for _ in range(args.depth * args.group):
+            runner.prefetch(x, flush=False)
 
     gathered = torch.empty(world * pairs_per_step, 8, device=dev) if world > 1 else None
 

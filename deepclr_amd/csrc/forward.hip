@@ -1,0 +1,61 @@
+// The dense stages of one batch behind a single entry point (host-side launch sequencing only; the
+// kernels are the ones of knn.hip, gemm.hip / gemm16.hip and flow.hip / flow16.hip).
+//
+// Reference call order: DeepCLR.forward -> merge layers (/root/reference/deepclr/models/deepclr.py:502-506):
+// MotionEmbedding (kNN grouping 149-171, shared MLP + mask + max 201-231), then OutputSimple (284-294).
+#include "common.h"
+
+extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, dclr_stream_t stream) {
+    DCLR_REQUIRE(a != nullptr);
+    DCLR_REQUIRE(a->pairs > 0 && a->npoint > 0 && a->n_head_layers >= 1 && a->n_head_layers <= DCLR_MERGE_MAX_LAYERS &&
+                 a->n_fc >= 1 && a->n_fc <= DCLR_MERGE_MAX_FC && (a->precision == 0 || a->precision == 1));
+    DCLR_REQUIRE(a->f_rows && a->pt && a->ps && a->knn_idx && a->e_rows && a->colmax && a->y && a->fc_tmp[0] && a->fc_tmp[1]);
+    hipStream_t st = (hipStream_t)stream;
+    int slot = 0;
+    auto mark = [&]() {
+        if (events && events[slot]) hipEventRecord((hipEvent_t)events[slot], st);
+        ++slot;
+    };
+    const int rows = a->pairs * a->npoint;
+    int rc;
+    mark();
+    // per-point halves of flow layer 1: W1b * feat_t (templates), W1c * feat_s (sources)
+    rc = dclr_linear(rows, 128, 64, a->f_rows, DCLR_F_STRIDE, a->wt, nullptr, 0, a->pt, 128, nullptr, 0, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    rc = dclr_linear(rows, 128, 64, a->f_rows + (size_t)rows * DCLR_F_STRIDE, DCLR_F_STRIDE, a->ws, nullptr, 0, a->ps,
+                     128, nullptr, 0, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    rc = dclr_knn_rows(a->pairs, a->npoint, a->k, a->f_rows, a->knn_idx, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    if (a->precision == 1)
+        rc = dclr_flow_embedding_fused_f16(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps,
+                                           a->w1a, a->b1, a->w2, a->b2, a->w3, a->b3, a->e_rows, stream);
+    else
+        rc = dclr_flow_embedding_fused(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps, a->w1a,
+                                       a->b1, (const float *)a->w2, a->b2, (const float *)a->w3, a->b3, a->e_rows, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    const int n_last = a->head_n[a->n_head_layers - 1];
+    if (hipMemsetAsync(a->colmax, 0, (size_t)a->pairs * n_last * sizeof(float), st) != hipSuccess)
+        return dclr_launch_status();
+    if (a->precision == 1)
+        rc = dclr_head_conv_fused_f16(rows, a->n_head_layers, a->head_k_in, a->head_k, a->head_n, a->head_w, a->head_b,
+                                      a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);
+    else
+        rc = dclr_head_conv_fused(rows, a->n_head_layers, a->head_k, a->head_n, (const float *const *)a->head_w, a->head_b,
+                                  a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    const float *x = a->colmax;
+    for (int l = 0; l < a->n_fc; ++l) {
+        float *out = l == a->n_fc - 1 ? a->y : a->fc_tmp[l & 1];
+        rc = dclr_fc(a->pairs, a->fc_n[l], a->fc_k[l], x, a->fc_w[l], a->fc_b[l], a->fc_act[l], out, stream);
+        if (rc != DCLR_OK) return rc;
+        mark();
+        x = out;
+    }
+    return DCLR_OK;
+}

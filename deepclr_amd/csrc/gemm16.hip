@@ -34,17 +34,18 @@ __global__ __launch_bounds__(256) void pack_weight_f16_kernel(int n_out, int k_i
 }
 
 // ---- fused conv chain ----------------------------------------------------------------------------------
-// Workgroup = 32 points through all layers, 8 waves (two per SIMD). Activations live in LDS as k-octets
-// (16 B hi | 16 B lo), ping-ponging between two buffers. Hidden layers compute W * X^T: the accumulator
-// lane is a point and its registers are 4 x 4 consecutive output channels, which are split and stored as
-// half-octets of the next layer's input (two ds_write_b64 per 4 channels). The last layer computes
-// X * W^T: lane = channel, registers = the 32 points, so the max over points is in-register plus one
+// Workgroup = 32 * MT points through all layers, 8 waves (two per SIMD). Activations live in ONE LDS buffer
+// as k-octets (16 B hi | 16 B lo) and are overwritten in place: a layer's outputs stay in the accumulators
+// until every wave has finished reading its inputs (wave w owns output tiles w and w + 8: at most
+// 2 x MT tiles = the whole layer for widths <= 512), then they are split and stored over them.
+// Hidden layers compute W * X^T: the accumulator lane is a point and its registers are 4 x 4 consecutive
+// output channels, i.e. half-octets of the next layer's input (two ds_write_b64 per 4 channels). The last
+// layer computes X * W^T: lane = channel, registers = points, so the max over points is in-register plus one
 // cross-half exchange, then one atomic max per channel.
-// Per k-step (16 values) a wave issues 4 weight-fragment loads (its 2 column tiles x hi/lo) for 6 MFMAs of
-// 32 cycles: with 8 waves that asks for ~85 B/clk/CU from L2, above the ~64 B/clk a CU's vector memory
-// path delivers, so the kernel is bound by weight delivery (4.2 MB per workgroup), not by the matrix pipe.
-constexpr int H16_WAVES = 8, H16_ROWS = 32, H16_MAX_LAYERS = 8, H16_MAX_WIDTH = 512;
-constexpr int H16_BUF = H16_ROWS * dclr_split_stride(H16_MAX_WIDTH);        // bytes per activation buffer
+// Weight delivery bounds the 32-point form (4.2 MB per workgroup through a ~64 B/clk vector memory path:
+// ~30 us, against ~22 us of MFMA); with MT = 2 the same stream feeds twice the MFMAs, the kernel turns
+// matrix-bound, needs only 128 CUs for 8192 rows and so keeps its speed while the sampler holds CUs.
+constexpr int H16_WAVES = 8, H16_MAX_LAYERS = 8, H16_MAX_WIDTH = 512;
 
 struct Head16Params {
     int n_layers;
@@ -55,58 +56,78 @@ struct Head16Params {
     const float *b[H16_MAX_LAYERS];
 };
 
-template <bool LAST, int NT>
-__device__ __forceinline__ void head16_panel(dclr_f32x16 (&acc)[2], dclr_f32x16 (&acc2)[2], const char *a_lane,
-                                             int kg, const float4 *wh_lane, const float4 *wl_lane, int tile_stride) {
-    // two named weight-fragment sets: set 1 is in flight while set 0 feeds the MFMAs (see mma.h)
-    dclr_h8 h0[NT], l0[NT], h1[NT], l1[NT];
+// K loop for NT weight tiles x MT point tiles. LAST: activations are the A operand (X * W^T).
+template <bool LAST, int NT, int MT>
+__device__ __forceinline__ void head16_panel(dclr_f32x16 (&acc)[2][MT], dclr_f32x16 (&acc2)[2][MT], const char *a_lane,
+                                             int tile_bytes, int kg, const float4 *wh_lane, const float4 *wl_lane,
+                                             int tile_stride) {
+    // Four weight-fragment sets in rotation, loads issued three k-steps ahead: a step is only 6-12 MFMAs
+    // (200-400 cycles), an L2 round trip under load is several times that, and the second wave of the SIMD
+    // stalls on its own fragments at about the same moments -- one step of lead leaves the matrix pipe idle
+    // about half the time. (Fixed set names through full unrolling: a rotating index makes hipcc fold the
+    // prefetch back into load-wait-use, see mma.h.)
+    dclr_h8 wh[4][NT], wl[4][NT];
+    auto fetch = [&](int g, dclr_h8 (&h)[NT], dclr_h8 (&l)[NT]) {
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride);
-        l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride);
-    }
-    auto step = [&](int g, const dclr_h8 (&wh)[NT], const dclr_h8 (&wl)[NT]) {
-        const dclr_h8 ah = dclr_lds_h8(a_lane + 64 * g), al = dclr_lds_h8(a_lane + 64 * g + 16);
-#pragma unroll
-        for (int u = 0; u < NT; ++u) acc[u] = LAST ? dclr_mfma32(ah, wh[u], acc[u]) : dclr_mfma32(wh[u], ah, acc[u]);
-#pragma unroll
-        for (int u = 0; u < NT; ++u) acc2[u] = LAST ? dclr_mfma32(ah, wl[u], acc2[u]) : dclr_mfma32(wl[u], ah, acc2[u]);
-#pragma unroll
-        for (int u = 0; u < NT; ++u) acc2[u] = LAST ? dclr_mfma32(al, wh[u], acc2[u]) : dclr_mfma32(wh[u], al, acc2[u]);
+        for (int u = 0; u < NT; ++u) {
+            h[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)g * 64);
+            l[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)g * 64);
+        }
     };
-    int g = 0;
-    for (; g + 2 <= kg; g += 2) {
+    auto step = [&](int g, const dclr_h8 (&h)[NT], const dclr_h8 (&l)[NT]) {
+        dclr_h8 ah[MT], al[MT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            h1[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
-            l1[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
+        for (int t = 0; t < MT; ++t) {
+            ah[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g);
+            al[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g + 16);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        step(g, h0, l0);
-        const int gn = g + 2 < kg ? g + 2 : g + 1;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)gn * 64);
-            l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)gn * 64);
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[u][t] = LAST ? dclr_mfma32(ah[t], h[u], acc[u][t]) : dclr_mfma32(h[u], ah[t], acc[u][t]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc2[u][t] = LAST ? dclr_mfma32(ah[t], l[u], acc2[u][t]) : dclr_mfma32(l[u], ah[t], acc2[u][t]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc2[u][t] = LAST ? dclr_mfma32(al[t], h[u], acc2[u][t]) : dclr_mfma32(h[u], al[t], acc2[u][t]);
+    };
+    fetch(0, wh[0], wl[0]);
+    fetch(kg > 1 ? 1 : 0, wh[1], wl[1]);
+    fetch(kg > 2 ? 2 : 0, wh[2], wl[2]);
+    for (int g = 0; g < kg; g += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (g + i < kg) {                                          // wave-uniform
+                const int ahead = g + i + 3 < kg ? g + i + 3 : kg - 1;  // clamped: the load stays unconditional
+                fetch(ahead, wh[(i + 3) & 3], wl[(i + 3) & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                step(g + i, wh[i], wl[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        step(g + 1, h1, l1);
     }
-    if (g < kg) step(g, h0, l0);
 }
 
+template <int MT>
 __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm, const float *__restrict__ x, int ldx,
                                                                 float *__restrict__ colmax, int rows_per_group) {
-    __shared__ __attribute__((aligned(16))) char act[2][H16_BUF];
+    constexpr int ROWS = 32 * MT;
+    __shared__ __attribute__((aligned(16))) char act[ROWS * dclr_split_stride(H16_MAX_WIDTH)];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
-    const int m0 = blockIdx.x * H16_ROWS;
+    const int m0 = blockIdx.x * ROWS;
 
-    // stage the 32 input rows: one k-octet (8 floats -> 16 B hi + 16 B lo) per thread and step
+    // stage the input rows: one k-octet (8 floats -> 16 B hi + 16 B lo) per thread and step
     {
         const int stride = dclr_split_stride(prm.k[0]);
         const int octets = prm.k[0] / 8, valid = prm.k_in / 8;
-        for (int e = tid; e < H16_ROWS * octets; e += H16_WAVES * 64) {
+        for (int e = tid; e < ROWS * octets; e += H16_WAVES * 64) {
             const int r = e / octets, o = e - r * octets;
             dclr_h8 hi, lo;
             if (o < valid) {
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { hi[q] = (_Float16)0.f; lo[q] = (_Float16)0.f; }
             }
-            char *dst = &act[0][r * stride + 32 * o];
+            char *dst = &act[r * stride + 32 * o];
             *reinterpret_cast<dclr_h8 *>(dst) = hi;
             *reinterpret_cast<dclr_h8 *>(dst + 16) = lo;
         }
@@ -131,56 +152,78 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
     __syncthreads();
 
     for (int l = 0; l < prm.n_layers; ++l) {
-        const char *in = act[l & 1];
-        char *out = act[(l & 1) ^ 1];
         const int kp = prm.k[l], n = prm.n[l], kg = kp / 16;
         const int in_stride = dclr_split_stride(kp), out_stride = dclr_split_stride(n);
         const bool last = l == prm.n_layers - 1;
-        const char *a_lane = in + j * in_stride + 32 * h;
+        const char *a_lane = act + j * in_stride + 32 * h;
         const int n_tiles = n / 32;
         const size_t plane = (size_t)n_tiles * kg * 64;                 // fragments per plane
-        for (int t0 = wave; t0 < n_tiles; t0 += 2 * H16_WAVES) {
-            const bool two = t0 + H16_WAVES < n_tiles;                  // wave-uniform
-            dclr_f32x16 acc[2] = {dclr_zero16(), dclr_zero16()}, acc2[2] = {dclr_zero16(), dclr_zero16()};
-            const float4 *wh = prm.w[l] + (size_t)t0 * kg * 64 + lane;
-            const float4 *wl = wh + plane;
-            const int ts = H16_WAVES * kg * 64;
-            if (last) {
-                if (two) head16_panel<true, 2>(acc, acc2, a_lane, kg, wh, wl, ts);
-                else head16_panel<true, 1>(acc, acc2, a_lane, kg, wh, wl, ts);
-            } else {
-                if (two) head16_panel<false, 2>(acc, acc2, a_lane, kg, wh, wl, ts);
-                else head16_panel<false, 1>(acc, acc2, a_lane, kg, wh, wl, ts);
-            }
+        const int ts = H16_WAVES * kg * 64;
+        if (!last) {
+            // hidden layer: this wave's tiles are w and w + 8 (n <= 512), results held until everyone has read
+            const int t0 = wave;
+            const bool any = t0 < n_tiles, two = t0 + H16_WAVES < n_tiles;      // wave-uniform
+            dclr_f32x16 acc[2][MT], acc2[2][MT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !two) break;
-                const int tt = t0 + u * H16_WAVES;
-                if (!last) {
-                    // lane = point j; registers 4 g4 + i = channel 32 tt + 8 g4 + 4 h + i
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) { acc[u][t] = dclr_zero16(); acc2[u][t] = dclr_zero16(); }
+            if (any) {
+                const float4 *wh = prm.w[l] + (size_t)t0 * kg * 64 + lane;
+                if (two) head16_panel<false, 2, MT>(acc, acc2, a_lane, 32 * in_stride, kg, wh, wh + plane, ts);
+                else head16_panel<false, 1, MT>(acc, acc2, a_lane, 32 * in_stride, kg, wh, wh + plane, ts);
+            }
+            __syncthreads();                                   // layer input fully consumed: overwrite in place
+            if (any) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    const int tt = t0 + u * H16_WAVES;
+                    // lane = point j of row tile t; registers 4 g4 + i = channel 32 tt + 8 g4 + 4 h + i
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int ch = 32 * tt + 8 * g4 + 4 * h;
                         const float4 bv = *reinterpret_cast<const float4 *>(prm.b[l] + ch);
                         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-                        dclr_h4 hi, lo;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = fmaxf(fmaf(acc2[u][4 * g4 + i], DCLR_SPLIT_INV, acc[u][4 * g4 + i]) + bb[i], 0.f);
-                            _Float16 a, b;
-                            dclr_split(v, a, b);
-                            hi[i] = a; lo[i] = b;
+                        for (int t = 0; t < MT; ++t) {
+                            dclr_h4 hi, lo;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = fmaxf(fmaf(acc2[u][t][4 * g4 + i], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i]) + bb[i], 0.f);
+                                _Float16 a, b;
+                                dclr_split(v, a, b);
+                                hi[i] = a; lo[i] = b;
+                            }
+                            char *dst = act + (32 * t + j) * out_stride + 32 * (4 * tt + g4) + 8 * h;
+                            *reinterpret_cast<dclr_h4 *>(dst) = hi;
+                            *reinterpret_cast<dclr_h4 *>(dst + 16) = lo;
                         }
-                        char *dst = out + j * out_stride + 32 * (4 * tt + g4) + 8 * h;
-                        *reinterpret_cast<dclr_h4 *>(dst) = hi;
-                        *reinterpret_cast<dclr_h4 *>(dst + 16) = lo;
                     }
-                } else {
+                }
+            }
+            __syncthreads();
+        } else {
+            for (int t0 = wave; t0 < n_tiles; t0 += 2 * H16_WAVES) {
+                const bool two = t0 + H16_WAVES < n_tiles;                  // wave-uniform
+                dclr_f32x16 acc[2][MT], acc2[2][MT];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) { acc[u][t] = dclr_zero16(); acc2[u][t] = dclr_zero16(); }
+                const float4 *wh = prm.w[l] + (size_t)t0 * kg * 64 + lane;
+                if (two) head16_panel<true, 2, MT>(acc, acc2, a_lane, 32 * in_stride, kg, wh, wh + plane, ts);
+                else head16_panel<true, 1, MT>(acc, acc2, a_lane, 32 * in_stride, kg, wh, wh + plane, ts);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
                     // lane = channel 32 tt + j; registers = points
-                    const int col = 32 * tt + j;
+                    const int col = 32 * (t0 + u * H16_WAVES) + j;
                     float mx = -3.0e38f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc2[u][r], DCLR_SPLIT_INV, acc[u][r]));
+                    for (int t = 0; t < MT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaf(acc2[u][t][r], DCLR_SPLIT_INV, acc[u][t][r]));
                     mx = fmaxf(mx + prm.b[l][col], 0.f);                // bias and ReLU commute with the maximum
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
                     if (h == 0)
@@ -189,7 +232,6 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -212,7 +254,7 @@ extern "C" int dclr_head_conv_fused_f16(int m, int n_layers, int k_in, const int
                                         const float *x, int ldx, float *colmax, int rows_per_group,
                                         dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n_layers >= 1 && k_host && n_host && w_packed_host && bias_host && x && colmax);
-    DCLR_REQUIRE(m % H16_ROWS == 0 && rows_per_group > 0 && rows_per_group % H16_ROWS == 0 && m % rows_per_group == 0);
+    DCLR_REQUIRE(m % 32 == 0 && rows_per_group > 0 && rows_per_group % 32 == 0 && m % rows_per_group == 0);
     DCLR_REQUIRE(k_in > 0 && k_in % 8 == 0 && ldx % 4 == 0 && ldx >= k_in && k_in <= k_host[0] && ((uintptr_t)x & 15) == 0);
     if (n_layers > H16_MAX_LAYERS) return DCLR_E_UNSUPPORTED;
     Head16Params prm{};
@@ -229,7 +271,12 @@ extern "C" int dclr_head_conv_fused_f16(int m, int n_layers, int k_in, const int
         prm.w[l] = reinterpret_cast<const float4 *>(w_packed_host[l]);
         prm.b[l] = bias_host[l];
     }
-    hipLaunchKernelGGL(head16_kernel, dim3(m / H16_ROWS), dim3(H16_WAVES * 64), 0, (hipStream_t)stream, prm, x, ldx,
-                       colmax, rows_per_group);
+    // 64 points per workgroup once that still gives every other CU a workgroup (and groups stay whole)
+    if (m >= 64 * 128 && rows_per_group % 64 == 0)
+        hipLaunchKernelGGL(head16_kernel<2>, dim3(m / 64), dim3(H16_WAVES * 64), 0, (hipStream_t)stream, prm, x, ldx,
+                           colmax, rows_per_group);
+    else
+        hipLaunchKernelGGL(head16_kernel<1>, dim3(m / 32), dim3(H16_WAVES * 64), 0, (hipStream_t)stream, prm, x, ldx,
+                           colmax, rows_per_group);
     return dclr_launch_status();
 }

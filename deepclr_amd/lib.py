@@ -40,9 +40,28 @@ SIGNATURES = {
     'dclr_pack_weight_f16': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_head_conv_fused_f16': [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     'dclr_flow_embedding_fused_f16': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dclr_merge_forward': [_p, _p, _p],
     'dclr_prepare_cloud_blocks': [_i, _i, _i],
     'dclr_prepare_cloud': [_i, _i, _p, _i, _i, _f, _f, _i, _p, _p, _p, _p],
 }
+
+MERGE_MAX_LAYERS, MERGE_MAX_FC = 8, 4
+MERGE_EVENTS = 6 + MERGE_MAX_FC
+
+
+class MergeArgs(ctypes.Structure):
+    """DclrMergeArgs (include/deepclr_amd.h)."""
+    _fields_ = [
+        ('pairs', _i), ('npoint', _i), ('k', _i), ('precision', _i), ('radius', _f),
+        ('n_head_layers', _i), ('head_k_in', _i), ('n_fc', _i),
+        ('head_k', _i * MERGE_MAX_LAYERS), ('head_n', _i * MERGE_MAX_LAYERS),
+        ('fc_k', _i * MERGE_MAX_FC), ('fc_n', _i * MERGE_MAX_FC), ('fc_act', _i * MERGE_MAX_FC),
+        ('f_rows', _p), ('wt', _p), ('ws', _p), ('w1a', _p), ('b1', _p), ('w2', _p), ('w3', _p), ('b2', _p), ('b3', _p),
+        ('head_w', _p * MERGE_MAX_LAYERS), ('head_b', _p * MERGE_MAX_LAYERS),
+        ('fc_w', _p * MERGE_MAX_FC), ('fc_b', _p * MERGE_MAX_FC),
+        ('pt', _p), ('ps', _p), ('knn_idx', _p), ('e_rows', _p), ('colmax', _p), ('fc_tmp', _p * 2), ('y', _p),
+    ]
+
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -11,6 +11,7 @@ and the per-module ``forward`` methods the reference's layer tests call).
 Out of scope here: losses (a ground truth ``y`` raises), backward, batch norm.
 """
 import abc
+import ctypes
 import os
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -18,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import lib, ops
 from ..config import Config
 from ..labels import LabelType
 from ..pointnet2 import PointnetSAModuleMSG
@@ -322,6 +323,71 @@ def _init_loss(cfg: Config, label_type: LabelType, **kwargs: Any) -> DeepCLRLoss
 
 # --------------------------------------------------------------------------------------------------
 # network
+class _MergePlan:
+    """Arguments + workspace of dclr_merge_forward for one (device, pairs, npoint, matrix path): built once,
+    reused by every batch of that shape (the workspace belongs to the stream the calls are enqueued on)."""
+
+    def __init__(self, args, keep, versions, pairs: int, n_out: int, device):
+        self.args, self._keep, self._versions = args, keep, versions
+        self._pairs, self._n_out, self._device = pairs, n_out, device
+
+    @staticmethod
+    def _version_key(mods):
+        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+    def current(self) -> bool:
+        return self._versions == self._version_key(self._keep['mods'])
+
+    @classmethod
+    def build(cls, flow, head, device, pairs: int, npoint: int):
+        rows = pairs * npoint
+        f16 = ops.PRECISION == 'f16x2'
+        layers = head._packed_f16() if f16 else head._packed()
+        if not head._fusable(head._packed(), rows, pairs) or (not f16 and rows < 4096):
+            return None
+        fcs = [(m.affine.weight, m.affine.bias, 1) for m in head.linear.layers()]
+        fcs.append((head.output.weight, head.output.bias, head._act))
+        if len(layers) > lib.MERGE_MAX_LAYERS or len(fcs) > lib.MERGE_MAX_FC or any(b is None for _, b, _ in fcs):
+            return None
+        p = flow._packed()
+        a = lib.MergeArgs()
+        a.pairs, a.npoint, a.k, a.precision, a.radius = pairs, npoint, flow._k, int(f16), flow._radius
+        a.n_head_layers, a.head_k_in, a.n_fc = len(layers), ops.E_STRIDE, len(fcs)
+        keep = {'mods': [flow, head], 'tensors': [p, layers]}
+
+        def dev(t):
+            t = t.detach().contiguous()
+            keep['tensors'].append(t)
+            return t.data_ptr()
+        for i, (wp, b, n, kp) in enumerate(layers):
+            a.head_k[i], a.head_n[i], a.head_w[i], a.head_b[i] = kp, n, wp.data_ptr(), b.data_ptr()
+        for i, (w, b, act) in enumerate(fcs):
+            a.fc_k[i], a.fc_n[i], a.fc_act[i], a.fc_w[i], a.fc_b[i] = w.shape[1], w.shape[0], act, dev(w), dev(b)
+        a.wt, a.ws, a.w1a, a.b1 = p['wt'].data_ptr(), p['ws'].data_ptr(), p['w1a'].data_ptr(), p['b1'].data_ptr()
+        a.w2, a.w3 = (p['w2h'] if f16 else p['w2p']).data_ptr(), (p['w3h'] if f16 else p['w3p']).data_ptr()
+        a.b2, a.b3 = p['b2'].data_ptr(), p['b3'].data_ptr()
+        width = max(w.shape[0] for w, _, _ in fcs)
+        ws = {'pt': torch.empty(rows, 128, device=device), 'ps': torch.empty(rows, 128, device=device),
+              'knn': torch.empty(pairs, npoint, flow._k, dtype=torch.int32, device=device),
+              'e': torch.empty(rows, ops.E_STRIDE, device=device),
+              'colmax': torch.empty(pairs, layers[-1][2], device=device),
+              'tmp': torch.empty(2, pairs, width, device=device)}
+        keep['ws'] = ws
+        a.pt, a.ps, a.knn_idx, a.e_rows = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr(), ws['e'].data_ptr()
+        a.colmax = ws['colmax'].data_ptr()
+        a.fc_tmp[0], a.fc_tmp[1] = ws['tmp'][0].data_ptr(), ws['tmp'][1].data_ptr()
+        return cls(a, keep, cls._version_key(keep['mods']), pairs, fcs[-1][0].shape[0], device)
+
+    def run(self, f_rows: torch.Tensor, events=None) -> torch.Tensor:
+        f_rows = lib.dev_f32(f_rows, 'f_rows')
+        if f_rows.shape != (2 * self._pairs * self.args.npoint, ops.F_STRIDE):
+            raise RuntimeError("feature rows do not match the planned batch shape")
+        y = torch.empty(self._pairs, self._n_out, device=self._device)
+        self.args.f_rows, self.args.y = f_rows.data_ptr(), y.data_ptr()
+        lib.check(lib.load().dclr_merge_forward(ctypes.byref(self.args), events, lib.stream_ptr()), 'merge_forward')
+        return y
+
+
 # --------------------------------------------------------------------------------------------------
 class DeepCLR(BaseModel):
     """Set abstraction over all 2B clouds -> flow embedding per pair -> pose head."""
@@ -339,6 +405,7 @@ class DeepCLR(BaseModel):
         head = _init_module(output, input_dim=merge_layer.output_dim(), label_type=label_type, **kwargs)
         self._cloud_layers = nn.Sequential(cloud)
         self._merge_layers = nn.Sequential(merge_layer, head)
+        self._plans: Dict[Any, Any] = {}
         if loss is None:
             self._loss_layer = None
         elif isinstance(loss, list):
@@ -368,9 +435,33 @@ class DeepCLR(BaseModel):
         """(2B, N, C) -> rows F ((2B)*npoint, 68); sample: precomputed self.sample(x), else computed here."""
         return self._cloud_layers[0].forward_rows(x, sample)
 
-    def merge_rows(self, f_rows: torch.Tensor, pairs: int) -> torch.Tensor:
+    def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None) -> torch.Tensor:
+        """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
+        OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
+        instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
+        plan = self._merge_plan(f_rows, pairs)
+        if plan is not None:
+            if events is None and ops.TIMER is not None:
+                events = ops.TIMER.merge_events(pairs * self.npoint)     # per-stage HIP events of a profiled step
+            return plan.run(f_rows, events)
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         return self._merge_layers[1].forward_rows(e_rows, pairs)
+
+    def _merge_plan(self, f_rows: torch.Tensor, pairs: int):
+        flow, head = self._merge_layers[0], self._merge_layers[1]
+        if os.environ.get('DCLR_MERGE_FUSED', '1') == '0' or not isinstance(flow, MotionEmbedding) \
+                or not isinstance(head, OutputSimple):
+            return None
+        key = (f_rows.device, pairs, self.npoint, ops.PRECISION)
+        plan = self._plans.get(key)
+        if plan is None or not plan.current():
+            plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint)
+            if plan is None:
+                return None
+            if len(self._plans) > 8:
+                self._plans.clear()
+            self._plans[key] = plan
+        return plan
 
     @property
     def label_dim(self) -> int:

@@ -7,6 +7,7 @@ batches i+1 .. i+depth on side HIP streams while set abstraction, flow embedding
 of batch i run on the main stream (the reference never batches or pipelines: one pair per call,
 /root/reference/deepclr/models/base.py:118-120, scripts/inference.py:100-104).
 """
+import os
 from collections import deque
 from typing import Deque, Iterable, Iterator, Optional, Tuple
 
@@ -16,37 +17,63 @@ from .models.deepclr import DeepCLR
 
 
 class PipelinedForward:
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features'):
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
         """ahead: what runs on the side streams -- 'sample' (sampling only) or 'features' (sampling + set
-        abstraction; the dense kernels of two batches then overlap and fill each other's tails)."""
+        abstraction; the dense kernels of two batches then overlap and fill each other's tails).
+        group: batches sampled by ONE launch (ahead='features' only). The sampler is a latency chain (~1 ms per
+        launch, one workgroup per cloud), so its throughput is launches in flight x clouds per launch; the HIP
+        runtime multiplexes streams onto 4 hardware queues, which caps the useful depth at 3 side streams --
+        grouping is how more clouds get in flight (their inputs are concatenated on the side stream)."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if ahead not in ('sample', 'features'):
             raise ValueError("ahead must be 'sample' or 'features'")
+        if group < 1 or (group > 1 and ahead != 'features'):
+            raise ValueError("group > 1 needs ahead='features'")
         self._model = model.eval()
         self.depth = depth
+        self.group = group
         self._ahead = ahead
-        self._streams = [torch.cuda.Stream() for _ in range(depth)]
+        self._waiting = []                          # batches collected for the next grouped launch
+        prio = int(os.environ.get('DCLR_SIDE_PRIORITY', '0'))
+        self._streams = [torch.cuda.Stream(priority=prio) for _ in range(depth)]
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
 
-    def prefetch(self, x: torch.Tensor) -> None:
-        """Start sampling for `x` (2B, N, C) on the next side stream."""
+    def prefetch(self, x: torch.Tensor, flush: bool = True) -> None:
+        """Start sampling for `x` (2B, N, C) on the next side stream (with group > 1: once `group` batches have
+        been handed in, or at once if flush)."""
+        self._waiting.append(x)
+        if len(self._waiting) >= self.group or flush:
+            self._launch()
+
+    def _launch(self) -> None:
+        """One sampling (+ set abstraction) launch for every batch collected so far."""
+        xs, self._waiting = self._waiting, []
+        if not xs:
+            return
         main = torch.cuda.current_stream()
         side = self._streams[self._next_stream]
         self._next_stream = (self._next_stream + 1) % self.depth
-        side.wait_stream(main)                               # x (and anything producing it) is ready
+        side.wait_stream(main)                               # the batches (and anything producing them) are ready
         with torch.cuda.stream(side), torch.no_grad():
-            out = self._model.sample(x)
-            if self._ahead == 'features':
-                out = self._model.cloud_feature_rows(x, out)
+            if len(xs) == 1:
+                out = self._model.sample(xs[0])
+                outs = [self._model.cloud_feature_rows(xs[0], out) if self._ahead == 'features' else out]
+            else:
+                if any(b.shape != xs[0].shape for b in xs):
+                    raise RuntimeError("batches sampled in one launch must have the same shape")
+                big = torch.cat(xs)
+                rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+                outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
             done = torch.cuda.Event()
             done.record(side)
-        x.record_stream(side)
-        self._pending.append((x, out, done))
+        for b, out in zip(xs, outs):
+            b.record_stream(side)
+            self._pending.append((b, out, done))
 
     def in_flight(self) -> int:
-        return len(self._pending)
+        return len(self._pending) + len(self._waiting)
 
     def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = ()) -> torch.Tensor:
         """Pose outputs (B, label_dim) for batch `x`. `upcoming` lists later batches (oldest first) that are
@@ -54,6 +81,8 @@ class PipelinedForward:
         stages are enqueued, so they run beside them."""
         main = torch.cuda.current_stream()
         ready = None
+        if not self._pending and self._waiting and self._waiting[0] is x:
+            self._launch()                                   # end of a stream of batches: the group never filled
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
             main.wait_event(done)
@@ -61,9 +90,9 @@ class PipelinedForward:
                 if t is not None:
                     t.record_stream(main)
         for nxt in upcoming:
-            if len(self._pending) >= self.depth:
+            if self.in_flight() >= self.depth * self.group:
                 break
-            self.prefetch(nxt)
+            self.prefetch(nxt, flush=False)
         with torch.no_grad():
             if ready is not None and self._ahead == 'features':
                 f_rows = ready
@@ -79,7 +108,7 @@ class PipelinedForward:
         window: Deque[torch.Tensor] = deque()
 
         def refill():
-            while len(window) < self.depth + 1:
+            while len(window) < self.depth * self.group + 1:
                 nxt = next(it, None)
                 if nxt is None:
                     break

@@ -205,6 +205,41 @@ int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, co
                                   const float *b1, const void *w2p, const float *b2, const void *w3p,
                                   const float *b3, float *e_rows, dclr_stream_t stream);
 
+/* ---- the dense stages of one batch in one call ----------------------------------------------------------
+ * Rows F of [templates..., sources...] -> pose outputs y (pairs, n_out): the launches DeepCLR.forward makes
+ * after set abstraction (reference: deepclr.py:502-506: merge layers = flow embedding, then the pose head)
+ * enqueued back to back on one stream -- per-point layer-1 products (2 x dclr_linear), dclr_knn_rows, the
+ * fused flow embedding, the fused conv chain + max over points, the fully connected tail. Exists because the
+ * host, not the GPU, bounds the step once these take ~0.25 ms: one foreign call and no allocation per batch.
+ * All buffers are the caller's; the workspace may be reused by the next call on the same stream.
+ * events: NULL, or DCLR_MERGE_EVENTS hipEvent_t handles recorded on `stream` before the first launch and after
+ * each stage (slot order: start, pt, ps, knn, flow, head, then one per fully connected layer). */
+#define DCLR_MERGE_MAX_LAYERS 8
+#define DCLR_MERGE_MAX_FC 4
+#define DCLR_MERGE_EVENTS (6 + DCLR_MERGE_MAX_FC)
+typedef struct DclrMergeArgs {
+    int pairs, npoint, k, precision;        /* precision: 0 = f32 matrix path, 1 = split-fp16 (f16x2) */
+    float radius;
+    int n_head_layers, head_k_in, n_fc;
+    int head_k[DCLR_MERGE_MAX_LAYERS], head_n[DCLR_MERGE_MAX_LAYERS];
+    int fc_k[DCLR_MERGE_MAX_FC], fc_n[DCLR_MERGE_MAX_FC], fc_act[DCLR_MERGE_MAX_FC];
+    const float *f_rows;                    /* (2 * pairs * npoint, DCLR_F_STRIDE) */
+    const float *wt, *ws;                   /* dclr_pack_weight of W1's template / source feature blocks (kp 64) */
+    const float *w1a, *b1;                  /* (128, 3) position block of layer 1, bias */
+    const void *w2, *w3;                    /* flow layers 2, 3: dclr_pack_weight16 (f32) or dclr_pack_weight_f16 */
+    const float *b2, *b3;
+    const void *head_w[DCLR_MERGE_MAX_LAYERS];      /* dclr_pack_weight (f32) or dclr_pack_weight_f16 (width 32) */
+    const float *head_b[DCLR_MERGE_MAX_LAYERS];
+    const float *fc_w[DCLR_MERGE_MAX_FC], *fc_b[DCLR_MERGE_MAX_FC];       /* row-major (n, k) */
+    float *pt, *ps;                         /* workspace (pairs * npoint, 128) each */
+    int32_t *knn_idx;                       /* workspace (pairs, npoint, k) */
+    float *e_rows;                          /* workspace (pairs * npoint, DCLR_E_STRIDE) */
+    float *colmax;                          /* workspace (pairs, head_n[last]) */
+    float *fc_tmp[2];                       /* workspace (pairs, max fc width) each */
+    float *y;                               /* out (pairs, fc_n[last]) */
+} DclrMergeArgs;
+int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
+
 /* ---- scan preparation (reference: CPU transforms run per sample before the model) -----------------------
  * One order-preserving pass over a raw scan raw (n_raw, c_raw): keep rows start, start+nth, ...
  * (SystematicErasing, /root/reference/deepclr/data/transforms/transforms.py:244-268), of those the rows with
