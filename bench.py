@@ -166,7 +166,8 @@ def main():
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
     ap.add_argument('--group', type=int, default=1, help='batches sampled by one launch on a side stream')
-    ap.add_argument('--ahead', default='features', choices=['sample', 'features'], help='stages run ahead')
+    ap.add_argument('--dense-streams', type=int, default=1, help='streams the dense stages alternate between')
+    ap.add_argument('--ahead', default='features', choices=['sample', 'features', 'knn'], help='stages run ahead')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -194,12 +195,12 @@ def main():
         if args.no_overlap:
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
         pairs_per_step = x.shape[0]
-        runner = PipelinedSequence(model, depth=args.depth, ahead=args.ahead)
+        runner = PipelinedSequence(model, depth=args.depth, ahead=args.ahead, group=1)
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
-                                                               group=args.group)
+                                                               group=args.group, dense_streams=args.dense_streams)
     if runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)

@@ -92,35 +92,49 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
         // channels 2 lane, 2 lane + 1 sit in octet lane / 4 at half positions 2 (lane % 4), + 1
         char *const slot = tile + 32 * (lane >> 2) + 4 * (lane & 3);
         if (live) {
+            // Three dependent L2 round trips for the whole point instead of one or two per neighbour:
+            // (1) the k neighbour indices, one per lane; (2) lane s fetches neighbour s's position, so the
+            // position differences, their norms and the radius mask are computed for all neighbours at once;
+            // (3) the k source halves of layer 1 (float2 per lane and neighbour), all requested before the
+            // first is used.
             const size_t pair = gp / npoint;
             const float *trow = f_rows + gp * DCLR_F_STRIDE;             // template clouds come first
             const float tx = trow[64], ty = trow[65], tz = trow[66];
+            const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
+            const int my_nb = lane < k ? knn_idx[gp * k + lane] : 0;
+            const float4 nbp = *reinterpret_cast<const float4 *>(f_rows + (src0 + my_nb) * DCLR_F_STRIDE + 64);
+            const float my_dx = nbp.x - tx, my_dy = nbp.y - ty, my_dz = nbp.z - tz;
+            const float norm = sqrtf(my_dx * my_dx + my_dy * my_dy + my_dz * my_dz);
+            bits = (uint32_t)__ballot(lane < k && (!(radius > 0.f) || norm < radius));
+            constexpr int KMAX = 4 * T;
+            float2 psv[KMAX];
+            const float *psrow = ps + pair * (size_t)npoint * F16_C + 2 * lane;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                const int nb = __builtin_amdgcn_readlane(my_nb, s < k ? s : 0);     // s >= k: a harmless repeat
+                psv[s] = *reinterpret_cast<const float2 *>(psrow + (size_t)nb * F16_C);
+            }
             const float2 ptv = *reinterpret_cast<const float2 *>(pt + gp * F16_C + 2 * lane);
             const float2 bv = *reinterpret_cast<const float2 *>(b1 + 2 * lane);
             const float wa0 = w1a[(2 * lane) * 3 + 0], wa1 = w1a[(2 * lane) * 3 + 1], wa2 = w1a[(2 * lane) * 3 + 2];
             const float wb0 = w1a[(2 * lane + 1) * 3 + 0], wb1 = w1a[(2 * lane + 1) * 3 + 1],
                         wb2 = w1a[(2 * lane + 1) * 3 + 2];
             const float base0 = ptv.x + bv.x, base1 = ptv.y + bv.y;
-            const int my_nb = lane < k ? knn_idx[gp * k + lane] : 0;
-            const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
-#pragma unroll 4
-            for (int s = 0; s < k; ++s) {
-                const int nb = __builtin_amdgcn_readlane(my_nb, s);
-                const float *srow = f_rows + (src0 + nb) * DCLR_F_STRIDE;
-                const float dx = srow[64] - tx, dy = srow[65] - ty, dz = srow[66] - tz;
-                const float2 psv = *reinterpret_cast<const float2 *>(ps + (pair * npoint + nb) * F16_C + 2 * lane);
-                float v0 = base0 + psv.x, v1 = base1 + psv.y;
-                v0 = fmaf(wa0, dx, v0); v0 = fmaf(wa1, dy, v0); v0 = fmaf(wa2, dz, v0);
-                v1 = fmaf(wb0, dx, v1); v1 = fmaf(wb1, dy, v1); v1 = fmaf(wb2, dz, v1);
-                dclr_h2 hi, lo;
-                _Float16 a, b;
-                dclr_split(fmaxf(v0, 0.f), a, b); hi[0] = a; lo[0] = b;
-                dclr_split(fmaxf(v1, 0.f), a, b); hi[1] = a; lo[1] = b;
-                const int row = (s >> 2) * 16 + 4 * p + (s & 3);
-                *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE) = hi;
-                *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE + 16) = lo;
-                const float norm = sqrtf(dx * dx + dy * dy + dz * dz);
-                if (!(radius > 0.f) || norm < radius) bits |= 1u << s;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                if (s < k) {                                             // wave-uniform
+                    const float dx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_dx), s));
+                    const float dy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_dy), s));
+                    const float dz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my_dz), s));
+                    float v0 = base0 + psv[s].x, v1 = base1 + psv[s].y;
+                    v0 = fmaf(wa0, dx, v0); v0 = fmaf(wa1, dy, v0); v0 = fmaf(wa2, dz, v0);
+                    v1 = fmaf(wb0, dx, v1); v1 = fmaf(wb1, dy, v1); v1 = fmaf(wb2, dz, v1);
+                    dclr_h2 hi, lo;
+                    dclr_split2_relu(v0, v1, hi, lo);
+                    const int row = (s >> 2) * 16 + 4 * p + (s & 3);
+                    *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE) = hi;
+                    *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE + 16) = lo;
+                }
             }
             s_done = k;
         }
@@ -137,28 +151,32 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
 
     // ---- phase B: layer 2 (128 -> 128), wave w owns channel tiles 2w, 2w+1 ---------------------------
     {
+        // registers i of tile u = channels (2 wave + u) * 16 + 4 kq + i: the accumulators start at the bias
         dclr_f32x4 acc[T][2], acc2[T][2];
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int u = 0; u < 2; ++u) {
+            const float4 bv = *reinterpret_cast<const float4 *>(b2 + (2 * wave + u) * 16 + 4 * kq);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { acc[t][u] = 0.f; acc2[t][u] = 0.f; }
+            for (int t = 0; t < T; ++t) {
+                acc[t][u][0] = bv.x; acc[t][u][1] = bv.y; acc[t][u][2] = bv.z; acc[t][u][3] = bv.w;
+                acc2[t][u] = 0.f;
+            }
+        }
         const float4 *wh = w2p + (size_t)(2 * wave) * F16_KG * 64 + lane;
         flow16_panel<T, true>(acc, acc2, a_lane, wh, wh + (size_t)(F16_C / 16) * F16_KG * 64, F16_KG * 64);
         __syncthreads();                                   // every wave has consumed the layer-1 rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int ch = (2 * wave + u) * 16 + 4 * kq;   // registers i = channels ch + i of neighbour row c16
-            const float4 bv = *reinterpret_cast<const float4 *>(b2 + ch);
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 dclr_h4 hi, lo;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = fmaxf(fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]) + bb[i], 0.f);
-                    _Float16 a, b;
-                    dclr_split(v, a, b);
-                    hi[i] = a; lo[i] = b;
+                for (int i = 0; i < 4; i += 2) {
+                    dclr_h2 a, b;
+                    dclr_split2_relu(fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]),
+                                     fmaf(acc2[t][u][i + 1], DCLR_SPLIT_INV, acc[t][u][i + 1]), a, b);
+                    hi[i] = a[0]; hi[i + 1] = a[1]; lo[i] = b[0]; lo[i + 1] = b[1];
                 }
                 char *dst = tile + (t * 16 + c16) * F16_STRIDE + 32 * (ch >> 3) + 2 * (ch & 7);
                 *reinterpret_cast<dclr_h4 *>(dst) = hi;

@@ -8,8 +8,10 @@
 extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, dclr_stream_t stream) {
     DCLR_REQUIRE(a != nullptr);
     DCLR_REQUIRE(a->pairs > 0 && a->npoint > 0 && a->n_head_layers >= 1 && a->n_head_layers <= DCLR_MERGE_MAX_LAYERS &&
-                 a->n_fc >= 1 && a->n_fc <= DCLR_MERGE_MAX_FC && (a->precision == 0 || a->precision == 1));
-    DCLR_REQUIRE(a->f_rows && a->pt && a->ps && a->knn_idx && a->e_rows && a->colmax && a->y && a->fc_tmp[0] && a->fc_tmp[1]);
+                 a->n_fc >= 1 && a->n_fc <= DCLR_MERGE_MAX_FC && (a->precision == 0 || a->precision == 1) &&
+                 a->stages >= 1 && a->stages <= 3);
+    DCLR_REQUIRE(a->f_rows && a->pt && a->ps && a->knn_idx);
+    DCLR_REQUIRE(!(a->stages & 2) || (a->e_rows && a->colmax && a->y && a->fc_tmp[0] && a->fc_tmp[1]));
     hipStream_t st = (hipStream_t)stream;
     int slot = 0;
     auto mark = [&]() {
@@ -19,17 +21,23 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     const int rows = a->pairs * a->npoint;
     int rc;
     mark();
-    // per-point halves of flow layer 1: W1b * feat_t (templates), W1c * feat_s (sources)
-    rc = dclr_linear(rows, 128, 64, a->f_rows, DCLR_F_STRIDE, a->wt, nullptr, 0, a->pt, 128, nullptr, 0, stream);
-    if (rc != DCLR_OK) return rc;
-    mark();
-    rc = dclr_linear(rows, 128, 64, a->f_rows + (size_t)rows * DCLR_F_STRIDE, DCLR_F_STRIDE, a->ws, nullptr, 0, a->ps,
-                     128, nullptr, 0, stream);
-    if (rc != DCLR_OK) return rc;
-    mark();
-    rc = dclr_knn_rows(a->pairs, a->npoint, a->k, a->f_rows, a->knn_idx, stream);
-    if (rc != DCLR_OK) return rc;
-    mark();
+    if (a->stages & 1) {
+        // per-point halves of flow layer 1: W1b * feat_t (templates), W1c * feat_s (sources)
+        rc = dclr_linear(rows, 128, 64, a->f_rows, DCLR_F_STRIDE, a->wt, nullptr, 0, a->pt, 128, nullptr, 0, stream);
+        if (rc != DCLR_OK) return rc;
+        mark();
+        rc = dclr_linear(rows, 128, 64, a->f_rows + (size_t)rows * DCLR_F_STRIDE, DCLR_F_STRIDE, a->ws, nullptr, 0,
+                         a->ps, 128, nullptr, 0, stream);
+        if (rc != DCLR_OK) return rc;
+        mark();
+        rc = dclr_knn_rows(a->pairs, a->npoint, a->k, a->f_rows, a->knn_idx, stream);
+        if (rc != DCLR_OK) return rc;
+        mark();
+    } else {
+        slot += 2;
+        mark();                             // slot 3 doubles as the start of the flow-embedding span
+    }
+    if (!(a->stages & 2)) return DCLR_OK;
     if (a->precision == 1)
         rc = dclr_flow_embedding_fused_f16(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps,
                                            a->w1a, a->b1, a->w2, a->b2, a->w3, a->b3, a->e_rows, stream);

@@ -135,10 +135,10 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
                 const float4 v1 = *reinterpret_cast<const float4 *>(x + (size_t)(m0 + r) * ldx + 8 * o + 4);
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    _Float16 a, b;
-                    dclr_split(v[q], a, b);
-                    hi[q] = a; lo[q] = b;
+                for (int q = 0; q < 8; q += 2) {
+                    dclr_h2 a, b;
+                    dclr_split2(v[q], v[q + 1], a, b);
+                    hi[q] = a[0]; hi[q + 1] = a[1]; lo[q] = b[0]; lo[q + 1] = b[1];
                 }
             } else {
 #pragma unroll
@@ -163,11 +163,23 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
             // hidden layer: this wave's tiles are w and w + 8 (n <= 512), results held until everyone has read
             const int t0 = wave;
             const bool any = t0 < n_tiles, two = t0 + H16_WAVES < n_tiles;      // wave-uniform
+            // registers 4 g4 + i of tile tt = channels 32 tt + 8 g4 + 4 h + i: the accumulators start at the bias
             dclr_f32x16 acc[2][MT], acc2[2][MT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                const int tt = t0 + u * H16_WAVES < n_tiles ? t0 + u * H16_WAVES : 0;
 #pragma unroll
-                for (int t = 0; t < MT; ++t) { acc[u][t] = dclr_zero16(); acc2[u][t] = dclr_zero16(); }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(prm.b[l] + 32 * tt + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        acc[u][t][4 * g4 + 0] = bv.x; acc[u][t][4 * g4 + 1] = bv.y;
+                        acc[u][t][4 * g4 + 2] = bv.z; acc[u][t][4 * g4 + 3] = bv.w;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc2[u][t] = dclr_zero16();
+            }
             if (any) {
                 const float4 *wh = prm.w[l] + (size_t)t0 * kg * 64 + lane;
                 if (two) head16_panel<false, 2, MT>(acc, acc2, a_lane, 32 * in_stride, kg, wh, wh + plane, ts);
@@ -182,18 +194,16 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
                     // lane = point j of row tile t; registers 4 g4 + i = channel 32 tt + 8 g4 + 4 h + i
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int ch = 32 * tt + 8 * g4 + 4 * h;
-                        const float4 bv = *reinterpret_cast<const float4 *>(prm.b[l] + ch);
-                        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                         for (int t = 0; t < MT; ++t) {
                             dclr_h4 hi, lo;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = fmaxf(fmaf(acc2[u][t][4 * g4 + i], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i]) + bb[i], 0.f);
-                                _Float16 a, b;
-                                dclr_split(v, a, b);
-                                hi[i] = a; lo[i] = b;
+                            for (int i = 0; i < 4; i += 2) {
+                                dclr_h2 a, b;
+                                dclr_split2_relu(fmaf(acc2[u][t][4 * g4 + i], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i]),
+                                                 fmaf(acc2[u][t][4 * g4 + i + 1], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i + 1]),
+                                                 a, b);
+                                hi[i] = a[0]; hi[i + 1] = a[1]; lo[i] = b[0]; lo[i + 1] = b[1];
                             }
                             char *dst = act + (32 * t + j) * out_stride + 32 * (4 * tt + g4) + 8 * h;
                             *reinterpret_cast<dclr_h4 *>(dst) = hi;

@@ -52,7 +52,7 @@ MERGE_EVENTS = 6 + MERGE_MAX_FC
 class MergeArgs(ctypes.Structure):
     """DclrMergeArgs (include/deepclr_amd.h)."""
     _fields_ = [
-        ('pairs', _i), ('npoint', _i), ('k', _i), ('precision', _i), ('radius', _f),
+        ('pairs', _i), ('npoint', _i), ('k', _i), ('precision', _i), ('stages', _i), ('radius', _f),
         ('n_head_layers', _i), ('head_k_in', _i), ('n_fc', _i),
         ('head_k', _i * MERGE_MAX_LAYERS), ('head_n', _i * MERGE_MAX_LAYERS),
         ('fc_k', _i * MERGE_MAX_FC), ('fc_n', _i * MERGE_MAX_FC), ('fc_act', _i * MERGE_MAX_FC),

@@ -378,13 +378,38 @@ class _MergePlan:
         a.fc_tmp[0], a.fc_tmp[1] = ws['tmp'][0].data_ptr(), ws['tmp'][1].data_ptr()
         return cls(a, keep, cls._version_key(keep['mods']), pairs, fcs[-1][0].shape[0], device)
 
-    def run(self, f_rows: torch.Tensor, events=None) -> torch.Tensor:
+    def _check(self, f_rows: torch.Tensor) -> torch.Tensor:
         f_rows = lib.dev_f32(f_rows, 'f_rows')
         if f_rows.shape != (2 * self._pairs * self.args.npoint, ops.F_STRIDE):
             raise RuntimeError("feature rows do not match the planned batch shape")
+        return f_rows
+
+    def prep(self, f_rows: torch.Tensor, events=None):
+        """Stage 1 alone (layer-1 halves + kNN) into buffers of its own -- what a side stream can run ahead."""
+        f_rows = self._check(f_rows)
+        rows, a = self._pairs * self.args.npoint, self.args
+        out = (torch.empty(rows, 128, device=self._device), torch.empty(rows, 128, device=self._device),
+               torch.empty(self._pairs, a.npoint, a.k, dtype=torch.int32, device=self._device))
+        ws = self._keep['ws']
+        a.f_rows, a.stages = f_rows.data_ptr(), 1
+        a.pt, a.ps, a.knn_idx = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+        try:
+            lib.check(lib.load().dclr_merge_forward(ctypes.byref(a), events, lib.stream_ptr()), 'merge_forward')
+        finally:
+            a.pt, a.ps, a.knn_idx = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr()
+        return out
+
+    def run(self, f_rows: torch.Tensor, events=None, prep=None) -> torch.Tensor:
+        f_rows = self._check(f_rows)
+        a, ws = self.args, self._keep['ws']
         y = torch.empty(self._pairs, self._n_out, device=self._device)
-        self.args.f_rows, self.args.y = f_rows.data_ptr(), y.data_ptr()
-        lib.check(lib.load().dclr_merge_forward(ctypes.byref(self.args), events, lib.stream_ptr()), 'merge_forward')
+        a.f_rows, a.y, a.stages = f_rows.data_ptr(), y.data_ptr(), 3 if prep is None else 2
+        if prep is not None:
+            a.pt, a.ps, a.knn_idx = prep[0].data_ptr(), prep[1].data_ptr(), prep[2].data_ptr()
+        try:
+            lib.check(lib.load().dclr_merge_forward(ctypes.byref(a), events, lib.stream_ptr()), 'merge_forward')
+        finally:
+            a.pt, a.ps, a.knn_idx = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr()
         return y
 
 
@@ -435,7 +460,16 @@ class DeepCLR(BaseModel):
         """(2B, N, C) -> rows F ((2B)*npoint, 68); sample: precomputed self.sample(x), else computed here."""
         return self._cloud_layers[0].forward_rows(x, sample)
 
-    def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None) -> torch.Tensor:
+    def merge_prep(self, f_rows: torch.Tensor, pairs: int):
+        """The part of merge_rows that needs nothing but the feature rows (per-point halves of flow layer 1, kNN),
+        for callers that run it ahead on another stream; None where the one-call path does not apply."""
+        plan = self._merge_plan(f_rows, pairs)
+        if plan is None:
+            return None
+        events = ops.TIMER.merge_events(pairs * self.npoint) if ops.TIMER is not None else None
+        return plan.prep(f_rows, events)
+
+    def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None, prep=None) -> torch.Tensor:
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
@@ -443,7 +477,7 @@ class DeepCLR(BaseModel):
         if plan is not None:
             if events is None and ops.TIMER is not None:
                 events = ops.TIMER.merge_events(pairs * self.npoint)     # per-stage HIP events of a profiled step
-            return plan.run(f_rows, events)
+            return plan.run(f_rows, events, prep)
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         return self._merge_layers[1].forward_rows(e_rows, pairs)
 
@@ -452,7 +486,8 @@ class DeepCLR(BaseModel):
         if os.environ.get('DCLR_MERGE_FUSED', '1') == '0' or not isinstance(flow, MotionEmbedding) \
                 or not isinstance(head, OutputSimple):
             return None
-        key = (f_rows.device, pairs, self.npoint, ops.PRECISION)
+        # the workspace belongs to one stream: calls enqueued on different streams may run side by side
+        key = (f_rows.device, pairs, self.npoint, ops.PRECISION, torch.cuda.current_stream().cuda_stream)
         plan = self._plans.get(key)
         if plan is None or not plan.current():
             plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint)

@@ -17,24 +17,35 @@ from .models.deepclr import DeepCLR
 
 
 class PipelinedForward:
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
-        """ahead: what runs on the side streams -- 'sample' (sampling only) or 'features' (sampling + set
-        abstraction; the dense kernels of two batches then overlap and fill each other's tails).
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
+                 dense_streams: int = 1):
+        """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
+        abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
+        the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
+        main stream is then left with the flow embedding, the head and the fully connected tail).
         group: batches sampled by ONE launch (ahead='features' only). The sampler is a latency chain (~1 ms per
         launch, one workgroup per cloud), so its throughput is launches in flight x clouds per launch; the HIP
         runtime multiplexes streams onto 4 hardware queues, which caps the useful depth at 3 side streams --
         grouping is how more clouds get in flight (their inputs are concatenated on the side stream)."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
-        if ahead not in ('sample', 'features'):
-            raise ValueError("ahead must be 'sample' or 'features'")
-        if group < 1 or (group > 1 and ahead != 'features'):
-            raise ValueError("group > 1 needs ahead='features'")
+        if ahead not in ('sample', 'features', 'knn'):
+            raise ValueError("ahead must be 'sample', 'features' or 'knn'")
+        if group < 1 or (group > 1 and ahead == 'sample'):
+            raise ValueError("group > 1 needs ahead='features' or 'knn'")
+        if dense_streams < 1 or (dense_streams > 1 and ahead == 'sample'):
+            raise ValueError("dense_streams > 1 needs ahead='features' or 'knn'")
         self._model = model.eval()
         self.depth = depth
         self.group = group
         self._ahead = ahead
         self._waiting = []                          # batches collected for the next grouped launch
+        # dense_streams > 1: the dense stages of consecutive batches alternate between that many streams, so the
+        # matrix-bound head of one batch runs beside the vector-bound flow embedding and the narrow kNN / fully
+        # connected launches of the next (one stream runs them strictly one after another, however little of
+        # the chip each of them fills); the caller's stream only waits for the result
+        self._dense_streams = [torch.cuda.Stream() for _ in range(dense_streams)] if dense_streams > 1 else []
+        self._next_dense = 0
         prio = int(os.environ.get('DCLR_SIDE_PRIORITY', '0'))
         self._streams = [torch.cuda.Stream(priority=prio) for _ in range(depth)]
         self._next_stream = 0
@@ -59,13 +70,15 @@ class PipelinedForward:
         with torch.cuda.stream(side), torch.no_grad():
             if len(xs) == 1:
                 out = self._model.sample(xs[0])
-                outs = [self._model.cloud_feature_rows(xs[0], out) if self._ahead == 'features' else out]
+                outs = [out if self._ahead == 'sample' else self._model.cloud_feature_rows(xs[0], out)]
             else:
                 if any(b.shape != xs[0].shape for b in xs):
                     raise RuntimeError("batches sampled in one launch must have the same shape")
                 big = torch.cat(xs)
                 rows = self._model.cloud_feature_rows(big, self._model.sample(big))
                 outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
+            if self._ahead == 'knn':
+                outs = [(rows, self._model.merge_prep(rows, b.shape[0] // 2)) for b, rows in zip(xs, outs)]
             done = torch.cuda.Event()
             done.record(side)
         for b, out in zip(xs, outs):
@@ -83,25 +96,47 @@ class PipelinedForward:
         ready = None
         if not self._pending and self._waiting and self._waiting[0] is x:
             self._launch()                                   # end of a stream of batches: the group never filled
+        lane = main
+        if self._dense_streams and self._pending and self._pending[0][0] is x:
+            lane = self._dense_streams[self._next_dense]
+            self._next_dense = (self._next_dense + 1) % len(self._dense_streams)
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
-            main.wait_event(done)
-            for t in (ready if isinstance(ready, tuple) else (ready,)):
-                if t is not None:
-                    t.record_stream(main)
+            lane.wait_event(done)
+            for t in self._tensors(ready):
+                t.record_stream(lane)
         for nxt in upcoming:
             if self.in_flight() >= self.depth * self.group:
                 break
             self.prefetch(nxt, flush=False)
         with torch.no_grad():
-            if ready is not None and self._ahead == 'features':
+            prep = None
+            if self._ahead == 'knn' and ready is not None:
+                ready, prep = ready
+            if lane is not main:
+                with torch.cuda.stream(lane):
+                    y = self._dense(ready, x, prep)
+                    finished = torch.cuda.Event()
+                    finished.record(lane)
+                main.wait_event(finished)
+                y.record_stream(main)
+                return y
+            if ready is not None and self._ahead != 'sample':
                 f_rows = ready
             else:
                 f_rows = self._model.cloud_feature_rows(x, ready)
-            return self._dense(f_rows, x)
+            return self._dense(f_rows, x, prep)
 
-    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        return self._model.merge_rows(f_rows, x.shape[0] // 2)
+    @staticmethod
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, (tuple, list)):
+            for o in obj:
+                yield from PipelinedForward._tensors(o)
+
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None) -> torch.Tensor:
+        return self._model.merge_rows(f_rows, x.shape[0] // 2, prep=prep)
 
     def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
         it = iter(batches)
@@ -132,14 +167,16 @@ class PipelinedSequence(PipelinedForward):
     runs one pair per call). step() returns the poses frame[i-1] -> frame[i] for the chunk: (T, label_dim),
     or (T-1, label_dim) for the first chunk after reset()."""
 
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features'):
-        super().__init__(model, depth, ahead)
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
+        if ahead == 'knn':
+            raise ValueError("pairs straddle chunk borders: the kNN stage cannot run per chunk ahead of time")
+        super().__init__(model, depth, ahead, group)         # one dense stream: chunk i + 1 needs chunk i's last frame
         self._carry: Optional[torch.Tensor] = None
 
     def reset(self) -> None:
         self._carry = None
 
-    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None) -> torch.Tensor:
         pair_rows, pairs, self._carry = self._model.sequence_rows(f_rows, x.shape[0], self._carry)
         if pairs == 0:
             return f_rows.new_empty(0, self._model.label_dim)

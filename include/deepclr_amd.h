@@ -219,6 +219,8 @@ int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, co
 #define DCLR_MERGE_EVENTS (6 + DCLR_MERGE_MAX_FC)
 typedef struct DclrMergeArgs {
     int pairs, npoint, k, precision;        /* precision: 0 = f32 matrix path, 1 = split-fp16 (f16x2) */
+    int stages;                             /* bit 0: layer-1 halves + kNN (fill pt, ps, knn_idx); bit 1: flow embedding,
+                                             * head, fully connected tail (consume them); 3 = everything */
     float radius;
     int n_head_layers, head_k_in, n_fc;
     int head_k[DCLR_MERGE_MAX_LAYERS], head_n[DCLR_MERGE_MAX_LAYERS];
