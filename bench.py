@@ -69,7 +69,7 @@ class LaunchTimer:
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
 
-    def merge_events(self, rows):
+    def merge_events(self, rows, n_fc=3):
         """Raw HIP events for the stages of one dclr_merge_forward call (the dense stages are one foreign call;
         the library records these between its launches, on the launch stream)."""
         if self.step % self.SAMPLE_EVERY != 0:
@@ -84,7 +84,7 @@ class LaunchTimer:
             if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
                 return None
             arr[i] = ev.value
-        names = ['linear[%dx128x64]' % rows] * 2 + ['knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * 4
+        names = ['linear[%dx128x64]' % rows] * 2 + ['knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * n_fc
         on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
         self.raw.append((arr, names, on_main))
         return arr
@@ -99,7 +99,8 @@ class LaunchTimer:
             for i, name in enumerate(names):
                 ms = ctypes.c_float()
                 if self._hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(arr[i]), ctypes.c_void_p(arr[i + 1])) != 0:
-                    continue                                  # slot not recorded (fewer fully connected layers)
+                    self._hip.hipGetLastError()               # slot not recorded (stage not run): clear, skip
+                    continue
                 tot, cnt, _ = acc.get(name, (0.0, 0, on_main))
                 acc[name] = (tot + ms.value, cnt + 1, on_main)
         return {k: {'total_ms': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1], 'main_stream': v[2]}
@@ -165,7 +166,7 @@ def main():
     ap.add_argument('--sequence', action='store_true',
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
-    ap.add_argument('--group', type=int, default=1, help='batches sampled by one launch on a side stream')
+    ap.add_argument('--group', type=int, default=2, help='batches sampled by one launch on a side stream')
     ap.add_argument('--dense-streams', type=int, default=1, help='streams the dense stages alternate between')
     ap.add_argument('--ahead', default='features', choices=['sample', 'features', 'knn'], help='stages run ahead')
     args = ap.parse_args()
@@ -315,7 +316,9 @@ def main():
                                     '(BASELINE.json configs[1])').format(x.shape[0], pairs_per_step)
                                    + '; kitti_00-06 architecture, seeded random weights',
                        'pairs_per_gpu': pairs_per_step, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world,
-                       'sampling_batches_ahead': 0 if runner is None else args.depth},
+                       'sampling_batches_ahead': 0 if runner is None else args.depth * (1 if args.sequence else args.group),
+                       'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
+                                                                1 if args.sequence else args.group, 'ahead': args.ahead}},
             'roofline': roofline,
         }
         if rooflines is not None:
