@@ -8,7 +8,7 @@
 // here nothing but the 64 pooled features per centroid ever leaves the CU.
 //
 // Workgroup = 4 waves x 4 centroids of one cloud.
-//   sweep   the cloud streams once per workgroup through double-buffered LDS tiles (512 points,
+//   sweep   the cloud streams once per workgroup through an LDS tile (256 points, next tile prefetched in registers,
 //           padded to float4); every wave tests each 64-point slice against its 4 centroids (scalar
 //           coordinates) and both radii. In-radius lanes are ballot-compacted, in ascending point
 //           order and capped at nsample per (centroid, scale) -- exactly the index set the published
@@ -32,13 +32,13 @@
 namespace {
 
 constexpr int SA_WAVES = 4;
-constexpr int SA_CPW = 8;                       // centroids per wave
-constexpr int SA_TILE = 512;                    // points per LDS tile
+constexpr int SA_CPW = 4;                       // centroids per wave
+constexpr int SA_TILE = 256;                    // points per LDS tile (one tile, two barriers per tile: the sweep is the
+                                                // rare path; 37 KB of LDS in all keep four workgroups on a CU)
 constexpr int SA_RING = 512;                    // ring capacity: < 64 left over + one centroid's neighbours (fast path) or
                                                 // + 4 slices staged between drain checks (sweep); power of two
 constexpr int SA_MAX_SCALES = 2;
 constexpr int SA_H1 = 16, SA_H2 = 16, SA_OUT = 32;
-constexpr int SA_OSTRIDE = SA_OUT + 1;          // output row: 32 channels + centroid tag, odd stride
 
 struct SaParams {
     int n, npoint, n_scales;
@@ -65,15 +65,22 @@ constexpr int SA_MLP_FLOATS = SA_H1 * 4 + SA_H1 + SA_H2 * SA_H1 + SA_H2 + SA_OUT
 
 // Workgroup-shared state. Namespace scope so that the (deliberately not inlined) drain routine can
 // address it; both template instances of the kernel use the same layout.
-__shared__ float4 sa_tile[2][SA_TILE];
+__shared__ float4 sa_tile[1][SA_TILE];
 __shared__ uint32_t sa_ring[SA_WAVES][SA_MAX_SCALES][SA_RING];
-__shared__ float sa_obuf[SA_WAVES][32 * SA_OSTRIDE];   // half a drain at a time: keeps 3 workgroups per CU
+__shared__ __attribute__((aligned(16))) float sa_obuf[SA_WAVES][64 * 4 + 64];   // drain staging: 64 inputs (float4) + 64 centroid tags
 __shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
 
 // running maxima per (wave, scale, centroid slot, channel): non-negative floats, compared as u32
 __shared__ uint32_t sa_acc[SA_WAVES][SA_MAX_SCALES][SA_CPW][SA_OUT];
 __shared__ int sa_tot[SA_WAVES][SA_CPW][SA_MAX_SCALES];
 __shared__ __attribute__((aligned(16))) float sa_w[SA_MAX_SCALES][SA_MLP_FLOATS];       // true neighbour counts of centroids done on the fast path
+
+#ifdef SA_DEBUG
+__device__ unsigned long long sa_dbg_w[16384][8];   // per wave, cycles: [0] total, [1] fast path incl. drains, [2] drains,
+                                                   // [3] #drains, [4] sweep, [5] 1, [6] drain: point load, [7] drain: MLP + fold
+__shared__ unsigned long long sa_dbg_l[4][2];
+#define SA_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#endif
 
 // One pass of the shared MLP over `take` (<= 64) ring entries of scale `s`; the results are folded into
 // sa_acc. Kept out of line on purpose (one copy, called from three places).
@@ -90,6 +97,10 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
     cloud = dclr_uniform(cloud);
     wave = dclr_uniform(wave); s = dclr_uniform(s); head = dclr_uniform(head); take = dclr_uniform(take);
     const int lane = dclr_lane(), e16 = lane & 15, kq = lane >> 4;
+#ifdef SA_DEBUG
+    unsigned long long g0, g1, g2, g3;
+    SA_STAMP(g0);
+#endif
     // stage the inputs (lane = entry): relative position + feature, and the centroid slot (-1: no entry)
     float *stg = sa_obuf[wave];
     int *tag = reinterpret_cast<int *>(stg + 256);
@@ -102,6 +113,10 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
             make_float4(p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w);
         tag[lane] = valid ? c : -1;
     }
+#ifdef SA_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SA_STAMP(g1);
+#endif
     const float *w1 = &sa_w[s][0];
     const float *b1 = w1 + SA_H1 * C, *w2 = b1 + SA_H1, *b2 = w2 + SA_H2 * SA_H1;
     const float *w3 = b2 + SA_H2, *b3 = w3 + SA_OUT * SA_H2;
@@ -116,6 +131,9 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         c3[0][j] = b3[4 * kq + j]; c3[1][j] = b3[16 + 4 * kq + j];
     }
     uint32_t *acc = &sa_acc[wave][s][0][0];
+#ifdef SA_DEBUG
+    SA_STAMP(g2);
+#endif
 #pragma unroll 1
     for (int t = 0; 16 * t < take; ++t) {
         const float x = stg[4 * (16 * t + e16) + kq];                        // input component kq of entry 16 t + e16
@@ -142,6 +160,10 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
                     atomicMax(acc + cen * SA_OUT + 16 * u + 4 * kq + i, __float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
         }
     }
+#ifdef SA_DEBUG
+    SA_STAMP(g3);
+    if (lane == 0) { sa_dbg_l[wave][0] += g1 - g0; sa_dbg_l[wave][1] += g3 - g2; }
+#endif
 }
 
 // Rounded lower bound of dclr_sqdist(c, p) over all p in the box (same operation order; rounding is monotone).
@@ -155,10 +177,6 @@ __device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz
     return s + zz;
 }
 
-#ifdef SA_DEBUG
-__device__ unsigned long long sa_dbg[8];       // cycles: [0] total, [1] fast path incl. drains, [2] drains, [3] #drains, [4] sweep, [5] #waves
-#define SA_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
-#endif
 
 template <int C>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
@@ -201,6 +219,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
     __syncthreads();
 
 #ifdef SA_DEBUG
+    if (lane == 0) { sa_dbg_l[wave][0] = 0; sa_dbg_l[wave][1] = 0; }
     unsigned long long t_begin, t_fast = 0, t_drain = 0, n_drain = 0, t_sweep = 0;
     SA_STAMP(t_begin);
 #endif
@@ -335,8 +354,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
         fetch(0);
         stash(0);
         for (int t = 0; t < n_tiles; ++t) {
-            __syncthreads();                               // tile t is in sa_tile[t & 1]
-            const int buf = t & 1;
+            __syncthreads();                               // tile t is in sa_tile
+            const int buf = 0;
             if (t + 1 < n_tiles) fetch(t + 1);
             for (int it = 0; it < SA_TILE / 64; ++it) {
                 const int k = t * SA_TILE + it * 64 + lane;
@@ -372,7 +391,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                     if ((c & 3) == 3 && __builtin_expect(qn[0] >= 64 || qn[1] >= 64, 0)) drain_all(false);
                 }
             }
-            if (t + 1 < n_tiles) stash(buf ^ 1);
+            __syncthreads();                               // every wave is done with tile t
+            if (t + 1 < n_tiles) stash(0);
         }
 #ifdef SA_DEBUG
         { unsigned long long w1; SA_STAMP(w1); t_sweep = w1 - w0; }
@@ -408,8 +428,9 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
 #ifdef SA_DEBUG
     if (lane == 0) {
         unsigned long long t_end; SA_STAMP(t_end);
-        atomicAdd(&sa_dbg[0], t_end - t_begin); atomicAdd(&sa_dbg[1], t_fast); atomicAdd(&sa_dbg[2], t_drain);
-        atomicAdd(&sa_dbg[3], n_drain); atomicAdd(&sa_dbg[4], t_sweep); atomicAdd(&sa_dbg[5], 1ull);
+        unsigned long long *o = sa_dbg_w[(blockIdx.y * gridDim.x + blockIdx.x) * SA_WAVES + wave];
+        o[0] = t_end - t_begin; o[1] = t_fast; o[2] = t_drain; o[3] = n_drain; o[4] = t_sweep; o[5] = 1ull;
+        o[6] = sa_dbg_l[wave][0]; o[7] = sa_dbg_l[wave][1];
     }
 #endif
 }

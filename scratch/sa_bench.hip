@@ -30,17 +30,18 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         unsigned long long zero[8] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg), zero, sizeof(zero));
+        { static std::vector<unsigned long long> z(16384 * 8, 0); hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg_w), z.data(), z.size() * 8); }
         hipEventRecord(e0);
         int rc2 = dclr_sa_msg_fused(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
                                     use_groups ? gb : nullptr, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long dbg[8];
-        hipMemcpyFromSymbol(dbg, HIP_SYMBOL(sa_dbg), sizeof(dbg));
+        { static std::vector<unsigned long long> w(16384 * 8); hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(sa_dbg_w), w.size() * 8);
+          for (int j = 0; j < 8; ++j) { dbg[j] = 0; for (int i = 0; i < 16384; ++i) dbg[j] += w[(size_t)i * 8 + j]; } }
         const double nw = dbg[5] ? (double)dbg[5] : 1;
-        printf("rc=%d/%d groups=%d  %.1f us | per wave (cycles): total %.0f  fast-path(incl drains) %.0f  drains %.0f (%.2f drains)  sweep %.0f | waves %.0f\n",
-               rc, rc2, (int)use_groups, ms * 1e3, dbg[0] / nw, dbg[1] / nw, dbg[2] / nw, dbg[3] / nw, dbg[4] / nw, nw);
+        printf("rc=%d/%d groups=%d  %.1f us | per wave (cycles): total %.0f  fast-path(incl drains) %.0f  drains %.0f (%.2f drains)  sweep %.0f | waves %.0f | inside drains: load %.0f mlp+fold %.0f\n",
+               rc, rc2, (int)use_groups, ms * 1e3, dbg[0] / nw, dbg[1] / nw, dbg[2] / nw, dbg[3] / nw, dbg[4] / nw, nw, dbg[6] / nw, dbg[7] / nw);
     }
     return 0;
 }
