@@ -254,7 +254,9 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, 
         for (int c = 0; c < FC_CHUNKS; ++c) wv[c] = c * 64 + lane < k ? wr[c * 64 + lane] : 0.f;
     }
     const float bv = (live && bias) ? bias[col] : 0.f;
-    for (int r0 = 0; r0 < m; r0 += FC_ROWS) {
+    // blockIdx.y strides over the row blocks: many rows (large batches of small clouds) spread over the grid
+    // instead of queueing inside one workgroup per column group
+    for (int r0 = blockIdx.y * FC_ROWS; r0 < m; r0 += gridDim.y * FC_ROWS) {
         const int rows = m - r0 < FC_ROWS ? m - r0 : FC_ROWS;
         __syncthreads();
         for (int r = 0; r < FC_ROWS; ++r)
@@ -354,7 +356,8 @@ extern "C" int dclr_fc(int m, int n, int k, const float *x, const float *w, cons
                        float *y, dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n > 0 && k > 0 && x && w && y && act >= 0 && act <= 3);
     if (k > FC_MAX_K) return DCLR_E_UNSUPPORTED;
-    hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES), dim3(FC_WAVES * 64), 0,
+    const int row_blocks = (m + FC_ROWS - 1) / FC_ROWS;
+    hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES, row_blocks < 64 ? row_blocks : 64), dim3(FC_WAVES * 64), 0,
                        (hipStream_t)stream, m, n, k, x, w, bias, act, y);
     return dclr_launch_status();
 }
