@@ -25,8 +25,10 @@ class PipelinedForward:
         main stream is then left with the flow embedding, the head and the fully connected tail).
         group: batches sampled by ONE launch (ahead='features' only). The sampler is a latency chain (~1 ms per
         launch, one workgroup per cloud), so its throughput is launches in flight x clouds per launch; the HIP
-        runtime multiplexes streams onto 4 hardware queues, which caps the useful depth at 3 side streams --
-        grouping is how more clouds get in flight (their inputs are concatenated on the side stream)."""
+        runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES; bench.py raises it to
+        8 so that RCCL's own stream does not share a queue with a sampling launch) and more than 3 side streams
+        measured slower either way -- grouping is how more clouds get in flight (their inputs are concatenated
+        on the side stream)."""
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if ahead not in ('sample', 'features', 'knn'):
