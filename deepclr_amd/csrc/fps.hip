@@ -537,16 +537,42 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #endif
                     float best = -1.0f;
                     int bjj = g * S;
+                    if constexpr (S % 2 == 0) {
+                        // two slots per instruction (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations in the
+                        // same order as dclr_sqdist, so the distances are bit-identical)
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const int jj = g * S + i;
-                        const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), cx, cy, cz);
-                        float d2;                           // plain v_min_f32: no canonicalising v_max in front of it
-                        asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
-                        vec_set<P>(td, jj, d2);
-                        const bool gt = d2 > best;
-                        bjj = gt ? jj : bjj;
-                        best = gt ? d2 : best;
+                        for (int i = 0; i < S; i += 2) {
+                            const int jj = g * S + i;
+                            const f2 ax = {vec_get<P>(px, jj), vec_get<P>(px, jj + 1)};
+                            const f2 ay = {vec_get<P>(py, jj), vec_get<P>(py, jj + 1)};
+                            const f2 az = {vec_get<P>(pz, jj), vec_get<P>(pz, jj + 1)};
+                            const f2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
+                            const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                            const f2 d = (xx + yy) + zz;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                float d2;                   // plain v_min_f32: no canonicalising v_max in front of it
+                                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d[h]), "v"(vec_get<P>(td, jj + h)));
+                                vec_set<P>(td, jj + h, d2);
+                                const bool gt = d2 > best;
+                                bjj = gt ? jj + h : bjj;
+                                best = gt ? d2 : best;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            const int jj = g * S + i;
+                            const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), cx, cy, cz);
+                            float d2;                       // plain v_min_f32: no canonicalising v_max in front of it
+                            asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                            vec_set<P>(td, jj, d2);
+                            const bool gt = d2 > best;
+                            bjj = gt ? jj : bjj;
+                            best = gt ? d2 : best;
+                        }
                     }
                     gbest[g] = best; gjj[g] = bjj;
                 }
