@@ -189,31 +189,40 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
     // ---- phase C: layer 3 (128 -> 256) + radius mask + max over neighbours; wave w owns channel tiles
     //      4w .. 4w+3, two at a time ------------------------------------------------------------------
     {
+        // Rows outside the radius are excluded from the maximum (reference: their outputs are zeroed, and the
+        // ReLU floor of the maximum is zero anyway). Done at accumulator start-up: a masked row begins at
+        // -3e38 instead of the bias, so it can never win -- the epilogue is then one fma and one max per value.
         const uint32_t vb = vbits[kq];                     // lane-quarter kq holds template point kq
         const size_t gp = g0 + kq;
+        bool keep[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) keep[t][i] = ((vb >> (4 * t + i)) & 1u) != 0;   // row 4 kq + i of tile t: neighbour 4t + i
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+            const int tile0 = 4 * wave + 2 * half;
             dclr_f32x4 acc[T][2], acc2[T][2];
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int u = 0; u < 2; ++u) {
+                const float bv = b3[(tile0 + u) * 16 + c16];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { acc[t][u] = 0.f; acc2[t][u] = 0.f; }
-            const int tile0 = 4 * wave + 2 * half;
+                for (int t = 0; t < T; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][u][i] = keep[t][i] ? bv : -3.0e38f;
+                    acc2[t][u] = 0.f;
+                }
+            }
             const float4 *wh = w3p + (size_t)tile0 * F16_KG * 64 + lane;
             flow16_panel<T, false>(acc, acc2, a_lane, wh, wh + (size_t)(F16_OUT / 16) * F16_KG * 64, F16_KG * 64);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int col = (tile0 + u) * 16 + c16;
-                const float bv = b3[col];
-                float mx = 0.f;                            // ReLU output floor; masked rows contribute 0
+                float mx = 0.f;                            // ReLU output floor
 #pragma unroll
                 for (int t = 0; t < T; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]) + bv;   // neighbour 4t + i
-                        mx = ((vb >> (4 * t + i)) & 1u) ? fmaxf(mx, v) : mx;
-                    }
-                if (gp < total) e_rows[gp * DCLR_E_STRIDE + col] = mx;
+                    for (int i = 0; i < 4; ++i) mx = fmaxf(mx, fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]));
+                if (gp < total) e_rows[gp * DCLR_E_STRIDE + (tile0 + u) * 16 + c16] = mx;
             }
         }
     }
