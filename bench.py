@@ -47,7 +47,8 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
 class LaunchTimer:
     """HIP events around every library launch, on the stream the kernel is enqueued on."""
 
-    SAMPLE_EVERY = 4       # bracket the launches of every 4th step only: the events themselves cost ~10 %
+    SAMPLE_EVERY = 5       # bracket the launches of every 5th step only (the events themselves cost ~10 %); coprime
+                           # with the 2-4 batches per sampling launch, or those launches would never be sampled
 
     def __init__(self, sample_every=None):
         self.spans = []
@@ -172,11 +173,11 @@ def main():
     ap.add_argument('--sequence', action='store_true',
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
-    ap.add_argument('--group', type=int, default=2, help='batches sampled by one launch on a side stream')
+    ap.add_argument('--group', type=int, default=4, help='batches sampled by one launch on a side stream')
     ap.add_argument('--dense-streams', type=int, default=1, help='streams the dense stages alternate between')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
-    ap.add_argument('--ahead', default='features', choices=['sample', 'features', 'knn'], help='stages run ahead')
+    ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -207,7 +208,8 @@ def main():
         if args.no_overlap:
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
         pairs_per_step = x.shape[0]
-        runner = PipelinedSequence(model, depth=args.depth, ahead=args.ahead, group=1)
+        runner = PipelinedSequence(model, depth=args.depth, ahead='features' if args.ahead == 'knn' else args.ahead,
+                                   group=1)
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
@@ -217,7 +219,8 @@ def main():
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
-    gathered = torch.empty(world * pairs_per_step, 8, device=dev) if use_dist else None
+    gathered = [torch.empty(world * pairs_per_step, 8, device=dev) for _ in range(2)] if use_dist else None
+
 
     def step():
         if runner is not None:
@@ -226,8 +229,8 @@ def main():
             with torch.no_grad():
                 y, _, _ = model(x)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, y)
-            return gathered
+            dist.all_gather_into_tensor(gathered[0], y)
+            return gathered[0]
         return y
 
     def fence():
