@@ -86,7 +86,14 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
             }
             const uint32_t li = (uint32_t)(c1 * 64 + lane);
             const uint32_t wmin = dclr_wave_min_u32(m1);
-            const uint32_t widx = dclr_wave_min_u32(m1 == wmin ? li : 0xFFFFFFFFu);
+            // one lane holds the minimum unless distances tie exactly: only then a second reduction picks the
+            // lowest candidate index among the holders
+            const uint64_t holders = __ballot(m1 == wmin);
+            uint32_t widx;
+            if (__builtin_popcountll(holders) == 1)
+                widx = (uint32_t)__builtin_amdgcn_readlane((int)li, __builtin_ctzll(holders));
+            else
+                widx = dclr_wave_min_u32(m1 == wmin ? li : 0xFFFFFFFFu);
             if (lane == 0) out(q, s, wmin >= KNN_INF ? -1 : (int)widx);
             if (lane == (int)(widx & 63)) {
                 used |= 1ull << (widx >> 6);
