@@ -15,7 +15,7 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     hipStream_t st = (hipStream_t)stream;
     int slot = 0;
     auto mark = [&]() {
-        if (events && events[slot]) hipEventRecord((hipEvent_t)events[slot], st);
+        if (events && events[slot]) (void)hipEventRecord((hipEvent_t)events[slot], st);
         ++slot;
     };
     const int rows = a->pairs * a->npoint;

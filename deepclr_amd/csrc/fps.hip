@@ -689,6 +689,279 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Kernel B: clouds too large for one CU's registers (16384 < n <= 65536). Same sampling rule, same
+// spatial pruning as kernel A', but the sorted points and their running minima live in a global
+// workspace (L2-resident, ~1.3 MB per cloud) and only the groups a round can change are touched:
+// a wave owns NG groups of 256 points (64 lanes x 4 slots), lane g keeps group g's box and an upper
+// bound of its largest running minimum, each lane keeps the largest running minimum of its 4 slots per
+// group (registers) and which slot holds it (2 bits per group). A round then reads and writes ~10 % of
+// the cloud instead of all of it (fps_stream_kernel: 1 MB per round through one CU's memory path).
+// ------------------------------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int m, const float *__restrict__ pts,
+                                                         int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
+                                                         float *__restrict__ std_all, uint32_t *__restrict__ sidx_all,
+                                                         uint16_t *__restrict__ cell_all) {
+    constexpr int WGS = 1024, NW = 16, P = 4 * NG, NP = WGS * P, BINS = 4096;
+    typedef typename VecOf<NG>::type gvec;
+    __shared__ unsigned long long cell[3];
+    __shared__ FpsCand cand[2][16];
+    __shared__ float red[6][16];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t hist[BINS];
+    extern __shared__ int32_t picked[];
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    pts += (size_t)blockIdx.x * n * pstride;
+    idx += (size_t)blockIdx.x * m;
+    float4 *spts = spts_all + (size_t)blockIdx.x * NP;
+    float *std_ = std_all + (size_t)blockIdx.x * NP;
+    uint32_t *sidx = sidx_all + (size_t)blockIdx.x * NP;
+    uint16_t *cellof = cell_all + (size_t)blockIdx.x * NP;
+
+    // ---- 1. bounding box ------------------------------------------------------------------------
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int k = t; k < n; k += WGS)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[(size_t)k * pstride + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = fps_shfl_min(lo[a]), h = fps_shfl_max(hi[a]);
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+    for (int u = t; u < BINS; u += WGS) hist[u] = 0u;
+    if (t < 3) cell[t] = 0ull;
+    if (t < 32) cand[t >> 4][t & 15] = FpsCand{0, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float ext = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = red[a][0], h = red[3 + a][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        lo[a] = l;
+        ext = fmaxf(ext, h - l);
+    }
+    // ---- 2. counting sort by 12-bit Morton cell (any order yields the same samples) ---------------
+    const float scale = ext > 0.f ? 15.999f / ext : 0.f;
+    for (int k = t; k < n; k += WGS) {
+        uint32_t q[3], mc = 0u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int c = (int)((pts[(size_t)k * pstride + a] - lo[a]) * scale);
+            q[a] = (uint32_t)(c < 0 ? 0 : (c > 15 ? 15 : c));
+        }
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit)
+            mc |= (((q[0] >> bit) & 1u) << (3 * bit)) | (((q[1] >> bit) & 1u) << (3 * bit + 1)) |
+                  (((q[2] >> bit) & 1u) << (3 * bit + 2));
+        atomicAdd(&hist[mc], 1u);
+        cellof[k] = (uint16_t)mc;
+    }
+    __syncthreads();
+    {
+        constexpr int BPT = BINS / WGS;
+        uint32_t c[BPT], mine = 0;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { c[u] = hist[BPT * t + u]; mine += c[u]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { hist[BPT * t + u] = run; run += c[u]; }
+    }
+    __syncthreads();
+    for (int k = t; k < n; k += WGS) sidx[atomicAdd(&hist[cellof[k]], 1u)] = (uint32_t)k;   // own cellof entries
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // ---- 3. groups: wave w owns sorted positions [w * 256 NG, (w + 1) * 256 NG); group g = 256 of them,
+    //         slot i of lane l = position base + 64 i + l, slots of a lane in ascending tie-key order ------
+    float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};   // lane g: box of group g
+    float gmaxv = 0.f;
+    gvec gbest;                                            // per lane: largest running minimum of the 4 slots
+    uint32_t gslot = 0;                                    // 2 bits per group: the slot holding it
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const int base = (wave * NG + g) * 256 + lane;
+        uint32_t tk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pos = base + 64 * i;
+            tk[i] = pos < n ? fps_tk1024(sidx[pos]) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k2 = 2; k2 <= 4; k2 <<= 1)
+#pragma unroll
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int l = i ^ j2;
+                    if (l > i) {
+                        const uint32_t a = tk[i], b = tk[l];
+                        const uint32_t mn = a < b ? a : b, mxv = a < b ? b : a;
+                        const bool asc = (i & k2) == 0;
+                        tk[i] = asc ? mn : mxv;
+                        tk[l] = asc ? mxv : mn;
+                    }
+                }
+        float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;    // -2: padding can never beat best = -1
+            uint32_t k = 0xFFFFFFFFu;
+            if (tk[i] != 0xFFFFFFFFu) {
+                k = fps_tk1024_inv(tk[i]);
+                x = pts[(size_t)k * pstride + 0];
+                y = pts[(size_t)k * pstride + 1];
+                z = pts[(size_t)k * pstride + 2];
+                d = 1e10f;
+                blo[0] = fminf(blo[0], x); blo[1] = fminf(blo[1], y); blo[2] = fminf(blo[2], z);
+                bhi[0] = fmaxf(bhi[0], x); bhi[1] = fmaxf(bhi[1], y); bhi[2] = fmaxf(bhi[2], z);
+                any = true;
+            }
+            spts[base + 64 * i] = make_float4(x, y, z, __uint_as_float(k));
+            std_[base + 64 * i] = d;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float l = fps_shfl_min(blo[a]), h = fps_shfl_max(bhi[a]);
+            if (lane == g) { glo[a] = l; ghi[a] = h; }
+        }
+        vec_set<NG>(gbest, g, any ? 0.f : -1.0f);
+        if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
+    }
+    // every thread re-reads only what it wrote itself (same positions): no further fence needed
+
+    float cx = pts[0], cy = pts[1], cz = pts[2];
+    if (t == 0) picked[0] = 0;
+    unsigned long long c_packed = (unsigned long long)wave;
+    int32_t c_k = 0;
+    float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+    int fresh = 0;
+    int c3 = 1;
+    for (int r = 1; r < m; ++r) {
+        const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], cx, cy, cz);
+        uint32_t act = (uint32_t)__ballot(lane < NG && lbv < gmaxv);
+        if (act != 0) {                                           // wave-uniform
+            for (uint32_t rem = act; rem != 0; rem &= rem - 1) {
+                const int g = __builtin_ctz(rem);
+                const int base = (wave * NG + g) * 256 + lane;
+                float4 q[4];
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { q[i] = spts[base + 64 * i]; o[i] = std_[base + 64 * i]; }
+                float best = -1.0f;
+                uint32_t bs = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = dclr_sqdist(q[i].x, q[i].y, q[i].z, cx, cy, cz);
+                    float d2;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(o[i]));
+                    std_[base + 64 * i] = d2;
+                    const bool gt = d2 > best;
+                    bs = gt ? (uint32_t)i : bs;
+                    best = gt ? d2 : best;
+                }
+                vec_set<NG>(gbest, g, best);
+                gslot = (gslot & ~(3u << (2 * g))) | (bs << (2 * g));
+            }
+            if ((r & 7) == 1) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float v = vec_get<NG>(gbest, g);
+                    const float gm = __uint_as_float(dclr_wave_max_u32(v < 0.f ? 0u : __float_as_uint(v)));
+                    gmaxv = lane == g ? gm : gmaxv;
+                }
+            }
+            // this lane's candidate: first group (lowest g) holding its largest running minimum
+            float lbest = vec_get<NG>(gbest, 0);
+#pragma unroll
+            for (int g = 1; g < NG; ++g) lbest = fmaxf(lbest, vec_get<NG>(gbest, g));
+            int hits = 0, hg = 0;
+#pragma unroll
+            for (int g = NG - 1; g >= 0; --g) {
+                const bool eq = vec_get<NG>(gbest, g) == lbest;
+                hits += eq ? 1 : 0;
+                hg = eq ? g : hg;
+            }
+            // fetch the candidate point (position, original index) while the wave reduction runs
+            const float4 mine4 = spts[(wave * NG + hg) * 256 + 64 * (int)((gslot >> (2 * hg)) & 3u) + lane];
+            const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
+            const float wmaxf = __uint_as_float(wmax);
+            const bool holder = lbest == wmaxf;
+            const uint64_t lanes_hit = __ballot(holder);
+            float4 win4;
+            int wl;
+            if (__builtin_popcountll(lanes_hit) == 1 && __ballot(holder && hits > 1) == 0) {
+                wl = __builtin_ctzll(lanes_hit);
+                win4 = mine4;
+            } else {
+                // exact tie: smallest tie key among all (lane, group) candidates carrying the maximum
+                uint32_t key = 0xFFFFFFFFu;
+                float4 k4 = mine4;
+#pragma unroll 1
+                for (int g = 0; g < NG; ++g) {
+                    if (__ballot(vec_get<NG>(gbest, g) == wmaxf) == 0) continue;      // wave-uniform
+                    float4 c4 = mine4;
+                    uint32_t kg = 0xFFFFFFFFu;
+                    if (vec_get<NG>(gbest, g) == wmaxf) {
+                        c4 = spts[(wave * NG + g) * 256 + 64 * (int)((gslot >> (2 * g)) & 3u) + lane];
+                        kg = fps_tk1024(__float_as_uint(c4.w));
+                    }
+                    const bool take = kg < key;
+                    key = take ? kg : key;
+                    k4 = take ? c4 : k4;
+                }
+                const uint32_t wk = dclr_wave_min_u32(key);
+                wl = __builtin_ctzll(__ballot(key == wk));
+                win4 = k4;
+            }
+            c_x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(win4.x), wl));
+            c_y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(win4.y), wl));
+            c_z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(win4.z), wl));
+            c_k = __builtin_amdgcn_readlane(__float_as_int(win4.w), wl);
+            const uint32_t wkey = fps_tk1024((uint32_t)c_k);
+            c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - wkey) << 16) |
+                       (unsigned long long)wave;
+            fresh = 2;
+        }
+        const int par = r & 1;
+        if (lane == 0) {
+            if (fresh > 0) cand[par][wave] = FpsCand{c_k, c_x, c_y, c_z};
+            atomicMax(&cell[c3], c_packed);
+            if (wave == 0) cell[c3 == 2 ? 0 : c3 + 1] = 0ull;
+        }
+        fresh = fresh > 0 ? fresh - 1 : 0;
+        __syncthreads();
+        const unsigned long long top = cell[c3];
+        const FpsCand w = cand[par][lane & 15];
+        const int wid = (int)__builtin_amdgcn_readfirstlane((uint32_t)top) & 15;
+        const int32_t wk = __builtin_amdgcn_readlane(w.k, wid);
+        cx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.x), wid));
+        cy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.y), wid));
+        cz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.z), wid));
+        if (t == 0) picked[r] = wk;
+        c3 = c3 == 2 ? 0 : c3 + 1;
+    }
+    __syncthreads();
+    for (int i = t; i < m; i += WGS) idx[i] = picked[i];
+}
+
 int fps_block(int n) {
     int t = 1;
     while (t * 2 <= n && t * 2 <= 1024) t *= 2;
@@ -768,6 +1041,41 @@ extern "C" int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, 
                                dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3);
     return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream);
+}
+
+// Workspace of the large-cloud sampler (kernel B): per cloud 1024 * P sorted points (float4), their running
+// minima (float), the sorted index list (u32) and the cell ids (u16); 0 where no workspace is used.
+static size_t fps_ws_bytes_per_cloud(int n) {
+    if (n <= 16384 || n > 65536) return 0;
+    const size_t np = n <= 32768 ? 32768 : 65536;
+    return np * (16 + 4 + 4 + 2);
+}
+
+extern "C" long long dclr_fps_workspace_bytes(int b, int n) {
+    if (b <= 0 || n <= 0) return DCLR_E_INVALID;
+    return (long long)(fps_ws_bytes_per_cloud(n) * (size_t)b);
+}
+
+extern "C" int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx, void *workspace,
+                                  long long workspace_bytes, dclr_stream_t stream) {
+    DCLR_REQUIRE(c >= 3 && b > 0 && n > 0 && m > 0 && clouds && idx);
+    const size_t need = fps_ws_bytes_per_cloud(n) * (size_t)b;
+    if (need == 0 || getenv("DCLR_FPS_PLAIN")) return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream);
+    DCLR_REQUIRE(workspace && workspace_bytes >= (long long)need && ((uintptr_t)workspace & 15) == 0);
+    if ((size_t)m * sizeof(int32_t) > 32 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] shares LDS with the histogram
+    const size_t np = n <= 32768 ? 32768 : 65536;
+    char *w = static_cast<char *>(workspace);
+    float4 *spts = reinterpret_cast<float4 *>(w);
+    float *stdv = reinterpret_cast<float *>(w + (size_t)b * np * 16);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(w + (size_t)b * np * 20);
+    uint16_t *cells = reinterpret_cast<uint16_t *>(w + (size_t)b * np * 24);
+    if (np == 32768)
+        hipLaunchKernelGGL((fps_paged_kernel<8>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), (hipStream_t)stream,
+                           n, c, m, clouds, idx, spts, stdv, sidx, cells);
+    else
+        hipLaunchKernelGGL((fps_paged_kernel<16>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), (hipStream_t)stream,
+                           n, c, m, clouds, idx, spts, stdv, sidx, cells);
+    return dclr_launch_status();
 }
 
 extern "C" int dclr_fps_group_layout(int n, int *n_groups, int *group_size) {

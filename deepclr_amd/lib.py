@@ -26,6 +26,8 @@ SIGNATURES = {
     'dclr_knn': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_fps_clouds': [_i, _i, _i, _i, _p, _p, _p],
     'dclr_fps_group_layout': [_i, _p, _p],
+    'dclr_fps_workspace_bytes': [_i, _i],
+    'dclr_fps_clouds_ws': [_i, _i, _i, _i, _p, _p, _p, ctypes.c_longlong, _p],
     'dclr_fps_clouds_grouped': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
@@ -78,7 +80,8 @@ def load() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = ctypes.c_char_p if name == 'dclr_error_string' else _i
+            fn.restype = (ctypes.c_char_p if name == 'dclr_error_string'
+                          else ctypes.c_longlong if name == 'dclr_fps_workspace_bytes' else _i)
         _lib = lib
     return _lib
 

@@ -118,10 +118,17 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor
 # level 2
 # ------------------------------------------------------------------------------------------------
 def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
-    """clouds (B, N, C>=3) interleaved -> (B, npoint) int32."""
+    """clouds (B, N, C>=3) interleaved -> (B, npoint) int32. Clouds of 16385..65536 points go through the
+    workspace variant (sorted points + running minima in a scratch buffer, only ~10 % of it touched per round)."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
+    need = lib.load().dclr_fps_workspace_bytes(b, n)
+    if need > 0 and npoint * 4 <= 32 * 1024:
+        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device)
+        _call('dclr_fps_clouds_ws', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+              need, lib.stream_ptr())
+        return idx
     _call('dclr_fps_clouds', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr())
     return idx
 

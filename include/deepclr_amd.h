@@ -102,6 +102,12 @@ int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *id
  * padding slot, coordinates 3e38); group_box (b, n_groups, 8) f32: min xyz, max xyz, 0, 0.
  * dclr_sa_msg_fused uses them to skip the exhaustive ball-query sweep. */
 int dclr_fps_group_layout(int n, int *n_groups, int *group_size);
+/* Large clouds (16384 < n <= 65536): same samples through a spatially pruned kernel whose sorted points and
+ * running minima live in a caller-provided workspace of dclr_fps_workspace_bytes(b, n) bytes (16-byte
+ * aligned; 0 bytes = size not covered, the call then equals dclr_fps_clouds). */
+long long dclr_fps_workspace_bytes(int b, int n);
+int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx, void *workspace,
+                       long long workspace_bytes, dclr_stream_t stream);
 int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,
                             float *group_pts, float *group_box, dclr_stream_t stream);
 

@@ -110,3 +110,18 @@ def test_ops_reject_cpu_tensors_and_bad_sizes():
         ops.knn(torch.zeros(4, 3, device=DEV), torch.zeros(4, 3, device=DEV), 8)     # fewer candidates than k
     with pytest.raises(RuntimeError):
         ops.ball_query(0.1, 4, torch.zeros(1, 8, 3, device=DEV).transpose(1, 2), torch.zeros(1, 2, 3, device=DEV))
+
+
+@pytest.mark.parametrize('kind,b,n,m', [
+    ('kitti', 2, 65536, 1024), ('normal', 2, 20000, 300), ('grid', 2, 40000, 500), ('dup', 2, 32768, 400),
+    ('kitti', 1, 16385, 200), ('normal', 1, 32769, 257), ('grid', 1, 65535, 64),
+])
+def test_fps_large_clouds_workspace_kernel_bit_exact(kind, b, n, m):
+    """16384 < n <= 65536: the spatially pruned kernel with its points in a workspace (ops.fps_clouds) against
+    the oracle and against the level-1 entry point (global-temp kernel)."""
+    xyz = _cloud(kind, b, n, seed=n + m)
+    want = oracle.furthest_point_sample(xyz, m)
+    x = xyz.to(DEV)
+    got = ops.fps_clouds(x, m).cpu()
+    assert torch.equal(got, want), 'first mismatch at {}'.format((got != want).nonzero()[:3].tolist())
+    assert torch.equal(ops.furthest_point_sample(x, m).cpu(), want)
