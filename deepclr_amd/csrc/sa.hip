@@ -292,12 +292,14 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 load_pair(m, q, nq);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bool valid = (u & 3) < slices && u < nq && __float_as_uint(q[u].w) != 0xFFFFFFFFu;
+                    if ((u & 3) >= slices || u >= nq) continue;            // clamped duplicate of another slice (uniform)
+                    // padding slots of a group hold x = y = z = 3e38: their distance is +inf, never a hit
                     const float d2 = dclr_sqdist(cx, cy, cz, q[u].x, q[u].y, q[u].z);
+                    if (__ballot(d2 < prm.radius2_max) == 0) continue;     // most slices: nothing inside the largest ball
 #pragma unroll
                     for (int s = 0; s < SA_MAX_SCALES; ++s) {
                         if (s >= prm.n_scales) break;
-                        const bool hit = valid && d2 < prm.radius2[s];
+                        const bool hit = d2 < prm.radius2[s];
                         const uint64_t mask = __ballot(hit);
                         if (mask != 0) {
                             const int add = __builtin_popcountll(mask);
