@@ -91,7 +91,7 @@ class LaunchTimer:
             if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
                 return None
             arr[i] = ev.value
-        names = ['linear[%dx128x64]' % rows] * 2 + ['knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * n_fc
+        names = ['linear_pair[2x%dx128x64]' % rows, None, 'knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * n_fc
         on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
         self.raw.append((arr, names, on_main))
         return arr
@@ -104,6 +104,8 @@ class LaunchTimer:
         import ctypes
         for arr, names, on_main in self.raw:
             for i, name in enumerate(names):
+                if name is None:
+                    continue
                 ms = ctypes.c_float()
                 if self._hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(arr[i]), ctypes.c_void_p(arr[i + 1])) != 0:
                     self._hip.hipGetLastError()               # slot not recorded (stage not run): clear, skip
@@ -120,6 +122,9 @@ def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int, clouds: in
     sa = cfg['params']['cloud_features']['params']
     npoint, k = sa['npoint'][0], cfg['params']['merge']['params']['k']
     c = cfg['input_dim']
+    if name.startswith('linear_pair'):
+        m, n, kk = (int(v) for v in name[name.index('[') + 3:-1].split('x'))
+        return 'mfma', 4.0 * m * n * kk
     if name.startswith('linear'):
         m, n, kk = (int(v) for v in name[name.index('[') + 1:-1].split('x'))
         return 'mfma', 2.0 * m * n * kk

@@ -22,13 +22,10 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     int rc;
     mark();
     if (a->stages & 1) {
-        // per-point halves of flow layer 1: W1b * feat_t (templates), W1c * feat_s (sources)
-        rc = dclr_linear(rows, 128, 64, a->f_rows, DCLR_F_STRIDE, a->wt, nullptr, 0, a->pt, 128, nullptr, 0, stream);
+        // per-point halves of flow layer 1: W1b * feat_t (templates), W1c * feat_s (sources), one launch
+        rc = dclr_linear_pair(rows, 128, 64, a->f_rows, DCLR_F_STRIDE, a->wt, a->ws, a->pt, a->ps, 128, stream);
         if (rc != DCLR_OK) return rc;
         mark();
-        rc = dclr_linear(rows, 128, 64, a->f_rows + (size_t)rows * DCLR_F_STRIDE, DCLR_F_STRIDE, a->ws, nullptr, 0,
-                         a->ps, 128, nullptr, 0, stream);
-        if (rc != DCLR_OK) return rc;
         mark();
         rc = dclr_knn_rows(a->pairs, a->npoint, a->k, a->f_rows, a->knn_idx, stream);
         if (rc != DCLR_OK) return rc;

@@ -61,9 +61,15 @@ __global__ __launch_bounds__(LIN_WAVES * 64) void linear_kernel(int m, int n, in
                                                                 int ldx, const float4 *__restrict__ wp,
                                                                 const float *__restrict__ bias, int relu,
                                                                 float *__restrict__ y, int ldy,
-                                                                float *__restrict__ colmax, int rows_per_group) {
+                                                                float *__restrict__ colmax, int rows_per_group,
+                                                                int m_split, const float4 *__restrict__ wp_hi,
+                                                                float *__restrict__ y_hi) {
     constexpr int BM = 32 * MT;
     __shared__ __attribute__((aligned(16))) float tile[2][BM * LIN_STRIDE];
+    if ((int)blockIdx.x * BM >= m_split) {                // second problem of a pair: rows m_split.. use their own
+        wp = wp_hi;                                       // weights and write to their own output (row 0 = m_split)
+        y = y_hi - (size_t)m_split * ldy;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int m0 = blockIdx.x * BM;
@@ -320,11 +326,28 @@ extern "C" int dclr_linear(int m, int n, int kp, const float *x, int ldx, const 
     DCLR_REQUIRE(gy <= 65535);
     if ((size_t)(m / LIN_BM) * gy < 1024)       // fewer than 4 workgroups per CU: halve the row tile
         hipLaunchKernelGGL((linear_kernel<1>), dim3(m / 32, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n, kp,
-                           x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax, rows_per_group);
+                           x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax, rows_per_group,
+                           0x7FFFFFFF, nullptr, nullptr);
     else
         hipLaunchKernelGGL((linear_kernel<2>), dim3(m / LIN_BM, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream, m, n,
                            kp, x, ldx, reinterpret_cast<const float4 *>(w_packed), bias, relu, y, ldy, colmax,
-                           rows_per_group);
+                           rows_per_group, 0x7FFFFFFF, nullptr, nullptr);
+    return dclr_launch_status();
+}
+
+// Two products over one row range in one launch: rows [0, m_each) with w_a -> y_a, rows [m_each, 2 m_each) with
+// w_b -> y_b (the template / source halves of flow layer 1). No bias, no activation.
+extern "C" int dclr_linear_pair(int m_each, int n, int kp, const float *x, int ldx, const float *w_a, const float *w_b,
+                                float *y_a, float *y_b, int ldy, dclr_stream_t stream) {
+    DCLR_REQUIRE(m_each > 0 && n > 0 && kp > 0 && x && w_a && w_b && y_a && y_b);
+    DCLR_REQUIRE(m_each % LIN_BM == 0 && kp % 8 == 0 && ldx % 4 == 0 && ldx >= kp && ldy >= n);
+    DCLR_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_a & 15) == 0 && ((uintptr_t)w_b & 15) == 0);
+    const int n_tiles = (n + 31) / 32;
+    const unsigned gy = (n_tiles + LIN_WAVES - 1) / LIN_WAVES;
+    DCLR_REQUIRE(gy <= 65535);
+    hipLaunchKernelGGL((linear_kernel<1>), dim3(2 * m_each / 32, gy), dim3(LIN_WAVES * 64), 0, (hipStream_t)stream,
+                       2 * m_each, n, kp, x, ldx, reinterpret_cast<const float4 *>(w_a), nullptr, 0, y_a, ldy, nullptr, 0,
+                       m_each, reinterpret_cast<const float4 *>(w_b), y_b);
     return dclr_launch_status();
 }
 

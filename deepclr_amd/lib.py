@@ -35,6 +35,7 @@ SIGNATURES = {
     'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_pack_weight16': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_linear': [_i, _i, _i, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p],
+    'dclr_linear_pair': [_i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p],
     'dclr_head_conv_fused': [_i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     'dclr_knn_rows': [_i, _i, _i, _p, _p, _p],
     'dclr_flow_embedding_fused': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

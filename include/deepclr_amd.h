@@ -155,6 +155,11 @@ int dclr_pack_weight16(int n_out, int k_in, const float *w, const int32_t *kmap,
 int dclr_linear(int m, int n, int kp, const float *x, int ldx, const float *w_packed, const float *bias,
                 int relu, float *y, int ldy, float *colmax, int rows_per_group, dclr_stream_t stream);
 
+/* Two dclr_linear products in one launch: rows [0, m_each) of x with w_a -> y_a, rows [m_each, 2 m_each) with w_b ->
+ * y_b; no bias, no activation (the template / source halves of flow layer 1). */
+int dclr_linear_pair(int m_each, int n, int kp, const float *x, int ldx, const float *w_a, const float *w_b,
+                     float *y_a, float *y_b, int ldy, dclr_stream_t stream);
+
 /* The whole 1x1-conv chain of the pose head in one launch (reference: OutputSimple.forward,
  * /root/reference/deepclr/models/deepclr.py:286-287): x rows (m, ldx) -> n_layers x [affine + ReLU] ->
  * column maxima per group of rows_per_group rows into colmax (m / rows_per_group, n_last), which the caller
