@@ -179,7 +179,6 @@ def main():
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
     ap.add_argument('--group', type=int, default=4, help='batches sampled by one launch on a side stream')
-    ap.add_argument('--dense-streams', type=int, default=1, help='streams the dense stages alternate between')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
@@ -219,7 +218,7 @@ def main():
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
-                                                               group=args.group, dense_streams=args.dense_streams)
+                                                               group=args.group)
     if runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)

@@ -17,13 +17,12 @@ from .models.deepclr import DeepCLR
 
 
 class PipelinedForward:
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
-                 dense_streams: int = 1):
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
         """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
         abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
         the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
         main stream is then left with the flow embedding, the head and the fully connected tail).
-        group: batches sampled by ONE launch (ahead='features' only). The sampler is a latency chain (~1 ms per
+        group: batches sampled by ONE launch (not with ahead='sample'). The sampler is a latency chain (~1 ms per
         launch, one workgroup per cloud), so its throughput is launches in flight x clouds per launch; the HIP
         runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES; bench.py raises it to
         8 so that RCCL's own stream does not share a queue with a sampling launch) and more than 3 side streams
@@ -35,19 +34,11 @@ class PipelinedForward:
             raise ValueError("ahead must be 'sample', 'features' or 'knn'")
         if group < 1 or (group > 1 and ahead == 'sample'):
             raise ValueError("group > 1 needs ahead='features' or 'knn'")
-        if dense_streams < 1 or (dense_streams > 1 and ahead == 'sample'):
-            raise ValueError("dense_streams > 1 needs ahead='features' or 'knn'")
         self._model = model.eval()
         self.depth = depth
         self.group = group
         self._ahead = ahead
         self._waiting = []                          # batches collected for the next grouped launch
-        # dense_streams > 1: the dense stages of consecutive batches alternate between that many streams, so the
-        # matrix-bound head of one batch runs beside the vector-bound flow embedding and the narrow kNN / fully
-        # connected launches of the next (one stream runs them strictly one after another, however little of
-        # the chip each of them fills); the caller's stream only waits for the result
-        self._dense_streams = [torch.cuda.Stream() for _ in range(dense_streams)] if dense_streams > 1 else []
-        self._next_dense = 0
         prio = int(os.environ.get('DCLR_SIDE_PRIORITY', '0'))
         self._streams = [torch.cuda.Stream(priority=prio) for _ in range(depth)]
         self._next_stream = 0
@@ -98,15 +89,11 @@ class PipelinedForward:
         ready = None
         if not self._pending and self._waiting and self._waiting[0] is x:
             self._launch()                                   # end of a stream of batches: the group never filled
-        lane = main
-        if self._dense_streams and self._pending and self._pending[0][0] is x:
-            lane = self._dense_streams[self._next_dense]
-            self._next_dense = (self._next_dense + 1) % len(self._dense_streams)
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
-            lane.wait_event(done)
+            main.wait_event(done)
             for t in self._tensors(ready):
-                t.record_stream(lane)
+                t.record_stream(main)
         for nxt in upcoming:
             if self.in_flight() >= self.depth * self.group:
                 break
@@ -115,14 +102,6 @@ class PipelinedForward:
             prep = None
             if self._ahead == 'knn' and ready is not None:
                 ready, prep = ready
-            if lane is not main:
-                with torch.cuda.stream(lane):
-                    y = self._dense(ready, x, prep)
-                    finished = torch.cuda.Event()
-                    finished.record(lane)
-                main.wait_event(finished)
-                y.record_stream(main)
-                return y
             if ready is not None and self._ahead != 'sample':
                 f_rows = ready
             else:
@@ -172,7 +151,7 @@ class PipelinedSequence(PipelinedForward):
     def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
         if ahead == 'knn':
             raise ValueError("pairs straddle chunk borders: the kNN stage cannot run per chunk ahead of time")
-        super().__init__(model, depth, ahead, group)         # one dense stream: chunk i + 1 needs chunk i's last frame
+        super().__init__(model, depth, ahead, group)
         self._carry: Optional[torch.Tensor] = None
 
     def reset(self) -> None:

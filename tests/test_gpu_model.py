@@ -341,9 +341,8 @@ def test_pipelined_runner_matches_plain_forward():
     batches = [torch.from_numpy(synthetic.make_batch('kitti', 2, 4096, first_pair=10 * i)).to(DEV) for i in range(5)]
     with torch.no_grad():
         want = [model(b)[0] for b in batches]
-    for ahead, group, lanes in (('sample', 1, 1), ('features', 1, 1), ('features', 2, 1), ('features', 3, 2),
-                                ('features', 1, 2), ('knn', 1, 1), ('knn', 2, 1)):
-        got = list(PipelinedForward(model, depth=2, ahead=ahead, group=group, dense_streams=lanes).run(batches))
+    for ahead, group in (('sample', 1), ('features', 1), ('features', 2), ('features', 3), ('knn', 1), ('knn', 2)):
+        got = list(PipelinedForward(model, depth=2, ahead=ahead, group=group).run(batches))
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
