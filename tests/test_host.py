@@ -153,3 +153,28 @@ def test_reference_import_names_resolve_to_this_package(tmp_path):
     with pytest.raises(RuntimeError):
         load_scenario(str(scen), with_method=True)
     assert isinstance(Evaluator(), deepclr_amd.evaluation.Evaluator)
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
+    """Argument validation comes first in every entry point: null pointers, sizes that break a stated relation and
+    unsupported shapes return DCLR_E_INVALID / DCLR_E_UNSUPPORTED (never a launch), so this runs without a GPU."""
+    handle = lib.load()
+    inval, unsup = -1, -2
+    assert handle.dclr_furthest_point_sampling(1, 8, 4, None, None, None, None) == inval
+    assert handle.dclr_ball_query(1, 8, 4, 0.5, 4, None, None, None, None) == inval
+    assert handle.dclr_knn(1, 8, 8, 4, None, None, None, None, None) == inval
+    assert handle.dclr_merge_forward(None, None, None) == inval
+    args = lib.MergeArgs()                                   # all zero: sizes invalid
+    assert handle.dclr_merge_forward(ctypes.byref(args), None, None) == inval
+    assert handle.dclr_prepare_cloud(10, 4, None, 1, 0, 0.0, 1.0, 4, None, None, None, None) == inval
+    assert handle.dclr_prepare_cloud_blocks(10, 2, 2) == inval          # start must be < nth
+    assert handle.dclr_prepare_cloud_blocks(4097, 2, 1) == 2 and handle.dclr_prepare_cloud_blocks(4099, 2, 1) == 3
+    assert handle.dclr_fps_workspace_bytes(2, 16384) == 0 and handle.dclr_fps_workspace_bytes(0, 100) == inval
+    assert handle.dclr_fps_workspace_bytes(2, 65536) == 2 * 65536 * 26
+    assert handle.dclr_fps_workspace_bytes(1, 20000) == 32768 * 26
+    n_groups, size = ctypes.c_int(0), ctypes.c_int(0)
+    assert handle.dclr_fps_group_layout(16384, ctypes.addressof(n_groups), ctypes.addressof(size)) == 0
+    assert (n_groups.value, size.value) == (64, 256)
+    assert handle.dclr_fps_group_layout(70000, ctypes.addressof(n_groups), ctypes.addressof(size)) == unsup
+    assert b'invalid argument' in handle.dclr_error_string(inval)
+    assert b'not supported' in handle.dclr_error_string(unsup)
