@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import lib, ops
+from .. import lib, losses, ops
 from ..config import Config
 from ..labels import LabelType
 from ..pointnet2 import PointnetSAModuleMSG
@@ -273,7 +273,7 @@ class OutputSimple(DeepCLRModule):
 
 
 # --------------------------------------------------------------------------------------------------
-# losses: parameter holders only (state_dict compatibility); evaluating them is out of scope
+# losses (forward values only: validation figures; there is no backward through the HIP kernels)
 # --------------------------------------------------------------------------------------------------
 class DeepCLRLoss(DeepCLRModule, metaclass=abc.ABCMeta):
     def output_dim(self) -> int:
@@ -282,24 +282,35 @@ class DeepCLRLoss(DeepCLRModule, metaclass=abc.ABCMeta):
     def get_weights(self) -> Dict:
         return {}
 
-    def forward(self, *_args: Any, **_kwargs: Any) -> torch.Tensor:
-        raise NotImplementedError("loss evaluation (training path) is outside the MI355X forward hot path")
-
 
 class TransformLoss(DeepCLRLoss):
+    """Fixed weights: sx * translation + sq * rotation (reference: deepclr.py:352-369)."""
+
     def __init__(self, label_type: LabelType, p: int, sx: float, sq: float, **_kwargs: Any):
         super().__init__()
+        self._label_type, self._p = label_type, p
         self._sx, self._sq = sx, sq
+
+    def forward(self, y_pred: torch.Tensor, y: torch.Tensor, **_kwargs: Any) -> torch.Tensor:
+        t, r = losses.transform_losses(y_pred, y, self._label_type, self._p)
+        return t * self._sx + r * self._sq
 
 
 class TransformUncertaintyLoss(DeepCLRLoss):
+    """Learned weights: t * exp(-sx) + sx + r * exp(-sq) + sq (reference: deepclr.py:372-389)."""
+
     def __init__(self, label_type: LabelType, p: int, sx: float, sq: float, **_kwargs: Any):
         super().__init__()
+        self._label_type, self._p = label_type, p
         self._sx = torch.nn.Parameter(torch.Tensor([sx]))
         self._sq = torch.nn.Parameter(torch.Tensor([sq]))
 
     def get_weights(self) -> Dict:
         return {'sx': self._sx.item(), 'sq': self._sq.item()}
+
+    def forward(self, y_pred: torch.Tensor, y: torch.Tensor, **_kwargs: Any) -> torch.Tensor:
+        t, r = losses.transform_losses(y_pred, y, self._label_type, self._p)
+        return t * torch.exp(-self._sx) + self._sx + r * torch.exp(-self._sq) + self._sq
 
 
 class AccumulatedLoss(DeepCLRLoss):
@@ -310,8 +321,14 @@ class AccumulatedLoss(DeepCLRLoss):
     def get_weights(self) -> Dict:
         weights: Dict = {}
         for loss in self.loss_list:
-            weights.update(loss.get_weights())
+            for key, value in loss.get_weights().items():
+                if key in weights:
+                    raise RuntimeError("Duplicate loss keys")
+                weights[key] = value
         return weights
+
+    def forward(self, *args: Any) -> torch.Tensor:
+        return torch.stack([loss(*args) for loss in self.loss_list], dim=0).sum()
 
 
 def _init_loss(cfg: Config, label_type: LabelType, **kwargs: Any) -> DeepCLRLoss:
@@ -530,8 +547,6 @@ class DeepCLR(BaseModel):
     def forward(self, x: torch.Tensor, is_feat: bool = False, m: Optional[torch.Tensor] = None,
                 y: Optional[torch.Tensor] = None, debug: bool = False)\
             -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Dict]]:
-        if y is not None and self._loss_layer is not None:
-            raise NotImplementedError("loss evaluation (training path) is outside the MI355X forward hot path")
         if x.shape[0] % 2 != 0:
             raise RuntimeError("batch must hold templates followed by the same number of sources")
         pairs = x.shape[0] // 2
@@ -541,4 +556,14 @@ class DeepCLR(BaseModel):
             if m is not None:
                 self._augment(x, m)
             f_rows = self.cloud_feature_rows(x.contiguous())
-        return self.merge_rows(f_rows, pairs), None, None
+        y_pred = self.merge_rows(f_rows, pairs)
+        if self._loss_layer is None or y is None:
+            return y_pred, None, None
+        # loss value as the reference returns it (deepclr.py:500-503); debug carries the (augmented, set-abstracted)
+        # clouds in the reference's channel layout
+        loss = self._loss_layer(y_pred, y)
+        aux = None
+        if debug:
+            feat = self._cloud_layers[0].output_dim() - 3
+            aux = {'x_aug': x if is_feat else ops.rows_to_channels(f_rows, x.shape[0], self.npoint, feat)}
+        return y_pred, loss, aux

@@ -109,6 +109,25 @@ def _ref_model(ref, cfg: dict, sd):
     return model, LabelType.create(cfg['label_type'])
 
 
+def loss_golden(ref, out_dir: str) -> None:
+    """Loss values of the reference's own loss modules (deepclr/models/deepclr.py:297-412 on utils/metrics.py)."""
+    LabelType = sys.modules['deepclr.data.labels'].LabelType
+    lt = LabelType.create('POSE3D_DUAL_QUAT')
+    rng = np.random.default_rng(5)
+    y_pred = torch.from_numpy(rng.normal(size=(8, 8)).astype(np.float32))
+    y = torch.from_numpy(rng.normal(size=(8, 8)).astype(np.float32))
+    out = {'y_pred': y_pred.numpy(), 'y': y.numpy()}
+    for p in (1, 2):
+        fixed = ref.TransformLoss(lt, p=p, sx=1.5, sq=40.0)
+        learned = ref.TransformUncertaintyLoss(lt, p=p, sx=0.3, sq=-2.5)
+        both = ref.AccumulatedLoss([fixed, ref.TransformLoss(lt, p=p, sx=0.5, sq=2.0)])   # same-shaped terms only
+        t, r = ref.TransformLossCalculation(lt, p)(y_pred, y)
+        out['p%d' % p] = np.array([t.item(), r.item(), fixed(y_pred, y).item(), learned(y_pred, y).item(),
+                                   both(y_pred, y).item()], dtype=np.float64)
+    np.savez_compressed(os.path.join(out_dir, 'losses.npz'), **out)
+    print('wrote losses.npz')
+
+
 def _sha(t: torch.Tensor) -> str:
     return hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
 
@@ -210,9 +229,13 @@ def run_case(ref, name, cfg, x_np, wseed, full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference', default='/root/reference')
+    ap.add_argument('--only-losses', action='store_true', help='regenerate losses.npz only')
     args = ap.parse_args()
     torch.set_num_threads(8)
     ref = _load_reference(args.reference)
+    loss_golden(ref, HERE)
+    if args.only_losses:
+        return
     for name, cfg_fn, x_fn, wseed, full in CASES:
         run_case(ref, name, cfg_fn(), x_fn(), wseed, full)
 

@@ -13,7 +13,7 @@ from deepclr_amd import ops, synthetic
 from deepclr_amd.config import model_config_from_dict
 from deepclr_amd.labels import LabelType
 from deepclr_amd.models import build_model, ModelInferenceHelper
-from helpers import GOLDEN_CASES, load_golden, case_cfg, degenerate_batch, pose_delta
+from helpers import GOLDEN_CASES, load_golden, case_cfg, degenerate_batch, pose_delta, small_cfg
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -411,3 +411,27 @@ def test_flow_embedding_split_fp16_against_f32_path_and_float64(k, radius):
     err16 = (e16[:, :256].double() - want).abs().max().item()
     _close(e16[:, :256], want.float().cpu())
     assert err16 <= 2 * err32 + 1e-7, (err16, err32)
+
+
+def test_forward_with_labels_returns_the_configured_loss():
+    """forward(x, y=labels) -> (y_pred, loss, debug) as in the reference (deepclr.py:488-508); no shipped model
+    configures an in-model loss, so the layer is added to the synthetic configuration here."""
+    from deepclr_amd import losses
+    cfg = small_cfg()
+    cfg['params']['loss'] = {'name': 'TransformUncertaintyLoss', 'params': {'p': 2, 'sx': 0.0, 'sq': -3.0}}
+    sd = synthetic.random_state_dict(small_cfg(), seed=3)
+    model = build_model(model_config_from_dict(cfg))
+    missing = model.load_state_dict(sd, strict=False)
+    assert sorted(missing.missing_keys) == ['_loss_layer._sq', '_loss_layer._sx'] and not missing.unexpected_keys
+    model = model.to(DEV).eval()
+    assert model.has_loss() and set(model.get_loss_weights()) == {'sx', 'sq'}
+    x = torch.from_numpy(synthetic.make_batch('kitti', 2, 512)).to(DEV)
+    labels = torch.tensor([[1.0, 0, 0, 0, 0, 0.1, 0, 0], [0.9, 0.1, 0, 0, 0, 0, 0.2, 0]], device=DEV)
+    with torch.no_grad():
+        y_pred, loss, dbg = model(x.clone(), y=labels, debug=True)
+        y_plain, none_loss, none_dbg = model(x.clone())
+    assert torch.equal(y_pred, y_plain) and none_loss is None and none_dbg is None
+    t, r = losses.transform_losses(y_pred, labels, LabelType.POSE3D_DUAL_QUAT, 2)
+    want = t * np.exp(0.0) + 0.0 + r * np.exp(3.0) - 3.0
+    torch.testing.assert_close(loss.reshape(()), want.reshape(()), rtol=1e-6, atol=1e-6)
+    assert dbg['x_aug'].shape == (4, 67, model.npoint)

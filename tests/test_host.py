@@ -178,3 +178,23 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert handle.dclr_fps_group_layout(70000, ctypes.addressof(n_groups), ctypes.addressof(size)) == unsup
     assert b'invalid argument' in handle.dclr_error_string(inval)
     assert b'not supported' in handle.dclr_error_string(unsup)
+
+
+def test_loss_values_match_reference_loss_modules():
+    """tests/golden/losses.npz holds values computed by the reference's TransformLoss / TransformUncertaintyLoss /
+    AccumulatedLoss on random dual-quaternion labels (make_golden.py); CPU tensors: the losses are plain torch."""
+    from deepclr_amd.models.deepclr import AccumulatedLoss, TransformLoss, TransformUncertaintyLoss
+    from deepclr_amd import losses
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'losses.npz'))
+    y_pred, y = torch.from_numpy(g['y_pred']), torch.from_numpy(g['y'])
+    lt = LabelType.POSE3D_DUAL_QUAT
+    for p in (1, 2):
+        t, r = losses.transform_losses(y_pred, y, lt, p)
+        fixed = TransformLoss(lt, p=p, sx=1.5, sq=40.0)
+        learned = TransformUncertaintyLoss(lt, p=p, sx=0.3, sq=-2.5)
+        both = AccumulatedLoss([fixed, TransformLoss(lt, p=p, sx=0.5, sq=2.0)])
+        got = np.array([t.item(), r.item(), fixed(y_pred, y).item(), learned(y_pred, y).item(), both(y_pred, y).item()])
+        np.testing.assert_allclose(got, g['p%d' % p], rtol=1e-6)
+        assert set(learned.get_weights()) == {'sx', 'sq'} and both.get_weights() == {}
+    with pytest.raises(RuntimeError):
+        losses.transform_losses(y_pred * float('nan'), y, lt, 2)
