@@ -17,6 +17,7 @@ constexpr int KNN_WAVES = 4;     // waves per workgroup
 constexpr int KNN_QRUN = 2;      // queries per wave
 constexpr int KNN_MAX_NX = 4096; // candidates staged in LDS (3 * 4 bytes each)
 constexpr uint32_t KNN_INF = 0x7F800000u;
+constexpr int KNN_LIMIT = 40;    // most lanes a selection threshold may let through (fast path of knn_block)
 
 struct KnnXyzSource {            // (clouds*n, 3) packed points
     const float *base;
@@ -29,8 +30,9 @@ struct KnnXyzSource {            // (clouds*n, 3) packed points
 struct KnnRowSource {            // feature rows F: xyz at columns 64..66 of a 68-float row
     const float *base;
     __device__ __forceinline__ void load(size_t cloud, int n, int i, float &x, float &y, float &z) const {
-        const float *p = base + (cloud * n + i) * DCLR_F_STRIDE + 64;
-        x = p[0]; y = p[1]; z = p[2];
+        // columns 64..67 of a row = x y z 0: one aligned 16-byte load (rows are 272 bytes)
+        const float4 v = *reinterpret_cast<const float4 *>(base + (cloud * n + i) * DCLR_F_STRIDE + 64);
+        x = v.x; y = v.y; z = v.z;
     }
 };
 
@@ -43,6 +45,7 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
     extern __shared__ float knn_lds[];                      // x[nxp] y[nxp] z[nxp], nxp = 64 * CPL
     constexpr int NXP = 64 * CPL;
     float *sx = knn_lds, *sy = knn_lds + NXP, *sz = knn_lds + 2 * NXP;
+    uint32_t *knn_compact = reinterpret_cast<uint32_t *>(knn_lds + 3 * NXP);    // per wave: 64 distances + 64 indices
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < NXP; i += KNN_WAVES * 64) {
         float x = 0.f, y = 0.f, z = 0.f;
@@ -62,6 +65,69 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
             // (candidate - query), accumulated x,y,z: the published kernel's order
             d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
         }
+        // Fast path: shrink the problem to <= 64 candidates, one per lane, then run the k arg-min rounds on those.
+        //  1. threshold: a value tau with k <= #lanes(lane minimum <= tau) <= KNN_LIMIT, found by a few pivot
+        //     tries (pivot = some lane's minimum, count = one ballot). Every lane counted holds a candidate
+        //     <= tau, so at least k candidates pass; the k nearest overall all pass (they are <= the k-th
+        //     smallest lane minimum <= tau).
+        //  2. all candidates <= tau are compacted (wave prefix sum, LDS) to one per lane -- typically 25-40 of
+        //     the 1024; more than 64 (heavy ties) or no suitable pivot falls back to the general selection.
+        //  3. k rounds of wave arg-min over one register per lane (ties: lowest candidate index).
+        bool fast = false;
+        {
+            uint32_t lmin = d[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) lmin = lmin < d[c] ? lmin : d[c];
+            uint32_t lo = 0u, hi = 0xFFFFFFFFu, tau = 0u;
+            bool first = true, found = false;
+#pragma unroll 1
+            for (int t = 0; t < 12 && !found; ++t) {
+                const uint64_t pool = __ballot(first || (lmin > lo && lmin < hi));
+                if (pool == 0) break;
+                const uint32_t piv = (uint32_t)__builtin_amdgcn_readlane((int)lmin, __builtin_ctzll(pool));
+                const int c = __builtin_popcountll(__ballot(lmin <= piv));
+                first = false;
+                if (c < k) lo = piv;
+                else if (c > KNN_LIMIT) hi = piv;
+                else { tau = piv; found = true; }
+            }
+            if (found && tau < KNN_INF) {
+                int cnt = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) cnt += d[c] <= tau ? 1 : 0;
+                int incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off);
+                    if (lane >= off) incl += up;
+                }
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total <= 64) {                                   // wave-uniform
+                    uint32_t *cd_lds = knn_compact + wave * 128, *ci_lds = cd_lds + 64;
+                    int pos = incl - cnt;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+                        if (d[c] <= tau) { cd_lds[pos] = d[c]; ci_lds[pos] = (uint32_t)(c * 64 + lane); ++pos; }
+                    // same wave wrote and reads: LDS operations of a wave complete in order
+                    uint32_t cd = lane < total ? cd_lds[lane] : 0xFFFFFFFFu;
+                    const uint32_t ci = lane < total ? ci_lds[lane] : 0xFFFFFFFFu;
+#pragma unroll 1
+                    for (int s = 0; s < k; ++s) {
+                        const uint32_t wmin = dclr_wave_min_u32(cd);
+                        const uint64_t holders = __ballot(cd == wmin);
+                        uint32_t widx;
+                        if (__builtin_popcountll(holders) == 1)
+                            widx = (uint32_t)__builtin_amdgcn_readlane((int)ci, __builtin_ctzll(holders));
+                        else
+                            widx = dclr_wave_min_u32(cd == wmin ? ci : 0xFFFFFFFFu);
+                        if (lane == 0) out(q, s, (int)widx);
+                        cd = ci == widx ? 0xFFFFFFFFu : cd;
+                    }
+                    fast = true;
+                }
+            }
+        }
+        if (fast) continue;
         // Each lane keeps its two nearest unused candidates (m1 <= m2, ties in index order); a round is then one
         // wave arg-min over m1 plus a pop in the winning lane. Only when a lane has been popped twice -- k picks
         // spread over 64 lanes: about once per query -- are the pairs rebuilt from the distance registers
@@ -148,7 +214,7 @@ struct XyzLauncher {
                   hipStream_t s) {
         const int per_wg = KNN_WAVES * KNN_QRUN;
         hipLaunchKernelGGL((knn_xyz_kernel<CPL>), dim3((ny + per_wg - 1) / per_wg, b), dim3(KNN_WAVES * 64),
-                           (size_t)3 * 64 * CPL * sizeof(float), s, nx, ny, k, x, y, row, col);
+                           (size_t)3 * 64 * CPL * sizeof(float) + KNN_WAVES * 128 * sizeof(uint32_t), s, nx, ny, k, x, y, row, col);
         return dclr_launch_status();
     }
 };
@@ -158,7 +224,7 @@ struct RowsLauncher {
     static int go(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx, hipStream_t s) {
         const int per_wg = KNN_WAVES * KNN_QRUN;
         hipLaunchKernelGGL((knn_rows_kernel<CPL>), dim3((npoint + per_wg - 1) / per_wg, pairs),
-                           dim3(KNN_WAVES * 64), (size_t)3 * 64 * CPL * sizeof(float), s, pairs, npoint, k, f_rows,
+                           dim3(KNN_WAVES * 64), (size_t)3 * 64 * CPL * sizeof(float) + KNN_WAVES * 128 * sizeof(uint32_t), s, pairs, npoint, k, f_rows,
                            knn_idx);
         return dclr_launch_status();
     }
