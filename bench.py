@@ -213,7 +213,7 @@ def main():
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
         pairs_per_step = x.shape[0]
         runner = PipelinedSequence(model, depth=args.depth, ahead='features' if args.ahead == 'knn' else args.ahead,
-                                   group=1)
+                                   group=args.group)
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
@@ -223,8 +223,7 @@ def main():
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
-    gathered = [torch.empty(world * pairs_per_step, 8, device=dev) for _ in range(2)] if use_dist else None
-
+    gathered = torch.empty(world * pairs_per_step, 8, device=dev) if use_dist else None
 
     def step():
         if runner is not None:
@@ -233,8 +232,8 @@ def main():
             with torch.no_grad():
                 y, _, _ = model(x)
         if use_dist:
-            dist.all_gather_into_tensor(gathered[0], y)
-            return gathered[0]
+            dist.all_gather_into_tensor(gathered, y)
+            return gathered
         return y
 
     def fence():
@@ -334,9 +333,9 @@ def main():
                                     '(BASELINE.json configs[1])').format(x.shape[0], pairs_per_step)
                                    + '; kitti_00-06 architecture, seeded random weights',
                        'pairs_per_gpu': pairs_per_step, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world,
-                       'sampling_batches_ahead': 0 if runner is None else args.depth * (1 if args.sequence else args.group),
+                       'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
                        'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
-                                                                1 if args.sequence else args.group, 'ahead': args.ahead}},
+                                                                args.group, 'ahead': args.ahead}},
             'roofline': roofline,
         }
         if rooflines is not None:
