@@ -179,6 +179,7 @@ def main():
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
     ap.add_argument('--group', type=int, default=4, help='batches sampled by one launch on a side stream')
+    ap.add_argument('--gather-every', type=int, default=4, help='steps whose outputs share one all-gather (N > 1)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
@@ -223,21 +224,36 @@ def main():
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
-    gathered = torch.empty(world * pairs_per_step, 8, device=dev) if use_dist else None
+    # all-gather once per GATHER_EVERY steps: the steps' outputs are written side by side into one send buffer
+    # (bigger, fewer collectives; every call makes the main stream wait for RCCL's stream)
+    gather_every = max(1, args.gather_every)
+    send = torch.zeros(gather_every, pairs_per_step, 8, device=dev) if use_dist else None
+    gathered = torch.empty(world * gather_every * pairs_per_step, 8, device=dev) if use_dist else None
+    counter = [0]
+
+    def flush():
+        dist.all_gather_into_tensor(gathered, send.view(-1, 8))
+        counter[0] = 0
 
     def step():
+        slot = send[counter[0]] if use_dist and runner is not None and not args.sequence else None
         if runner is not None:
-            y = runner.step(x, upcoming=[x])     # sampling of later batches overlaps the stages of this one
+            y = runner.step(x, upcoming=[x], out=slot)   # sampling of later batches overlaps the stages of this one
         else:
             with torch.no_grad():
                 y, _, _ = model(x)
         if use_dist:
-            dist.all_gather_into_tensor(gathered, y)
-            return gathered
+            if slot is None:
+                send[counter[0], :y.shape[0]].copy_(y[-pairs_per_step:] if y.shape[0] > pairs_per_step else y)
+            counter[0] += 1
+            if counter[0] == gather_every:
+                flush()
         return y
 
     def fence():
         if use_dist:
+            if counter[0]:
+                flush()
             dist.barrier()
         torch.cuda.synchronize()
 

@@ -416,10 +416,13 @@ class _MergePlan:
             a.pt, a.ps, a.knn_idx = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr()
         return out
 
-    def run(self, f_rows: torch.Tensor, events=None, prep=None) -> torch.Tensor:
+    def run(self, f_rows: torch.Tensor, events=None, prep=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         f_rows = self._check(f_rows)
         a, ws = self.args, self._keep['ws']
-        y = torch.empty(self._pairs, self._n_out, device=self._device)
+        if out is not None and (out.shape != (self._pairs, self._n_out) or not out.is_contiguous()
+                                or out.dtype != torch.float32 or out.device != f_rows.device):
+            raise RuntimeError("out must be a contiguous float32 (pairs, label_dim) tensor on the same device")
+        y = out if out is not None else torch.empty(self._pairs, self._n_out, device=self._device)
         a.f_rows, a.y, a.stages = f_rows.data_ptr(), y.data_ptr(), 3 if prep is None else 2
         if prep is not None:
             a.pt, a.ps, a.knn_idx = prep[0].data_ptr(), prep[1].data_ptr(), prep[2].data_ptr()
@@ -486,7 +489,8 @@ class DeepCLR(BaseModel):
         events = ops.TIMER.merge_events(pairs * self.npoint, plan.args.n_fc) if ops.TIMER is not None else None
         return plan.prep(f_rows, events)
 
-    def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None, prep=None) -> torch.Tensor:
+    def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None, prep=None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
@@ -494,9 +498,10 @@ class DeepCLR(BaseModel):
         if plan is not None:
             if events is None and ops.TIMER is not None:
                 events = ops.TIMER.merge_events(pairs * self.npoint, plan.args.n_fc)   # per-stage HIP events
-            return plan.run(f_rows, events, prep)
+            return plan.run(f_rows, events, prep, out)
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
-        return self._merge_layers[1].forward_rows(e_rows, pairs)
+        y = self._merge_layers[1].forward_rows(e_rows, pairs)
+        return y if out is None else out.copy_(y)
 
     def _merge_plan(self, f_rows: torch.Tensor, pairs: int):
         flow, head = self._merge_layers[0], self._merge_layers[1]

@@ -81,8 +81,9 @@ class PipelinedForward:
     def in_flight(self) -> int:
         return len(self._pending) + len(self._waiting)
 
-    def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = ()) -> torch.Tensor:
-        """Pose outputs (B, label_dim) for batch `x`. `upcoming` lists later batches (oldest first) that are
+    def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = (),
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Pose outputs (B, label_dim) for batch `x` (written into `out` if given). `upcoming` lists later batches (oldest first) that are
         not yet being sampled; as many as fit the pipeline depth are started before this batch's dense
         stages are enqueued, so they run beside them."""
         main = torch.cuda.current_stream()
@@ -106,7 +107,7 @@ class PipelinedForward:
                 f_rows = ready
             else:
                 f_rows = self._model.cloud_feature_rows(x, ready)
-            return self._dense(f_rows, x, prep)
+            return self._dense(f_rows, x, prep, out)
 
     @staticmethod
     def _tensors(obj):
@@ -116,8 +117,8 @@ class PipelinedForward:
             for o in obj:
                 yield from PipelinedForward._tensors(o)
 
-    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None) -> torch.Tensor:
-        return self._model.merge_rows(f_rows, x.shape[0] // 2, prep=prep)
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None, out=None) -> torch.Tensor:
+        return self._model.merge_rows(f_rows, x.shape[0] // 2, prep=prep, out=out)
 
     def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
         it = iter(batches)
@@ -157,8 +158,8 @@ class PipelinedSequence(PipelinedForward):
     def reset(self) -> None:
         self._carry = None
 
-    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None) -> torch.Tensor:
+    def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None, out=None) -> torch.Tensor:
         pair_rows, pairs, self._carry = self._model.sequence_rows(f_rows, x.shape[0], self._carry)
         if pairs == 0:
             return f_rows.new_empty(0, self._model.label_dim)
-        return self._model.merge_rows(pair_rows, pairs)
+        return self._model.merge_rows(pair_rows, pairs, out=out)
