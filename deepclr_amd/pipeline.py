@@ -7,7 +7,6 @@ batches i+1 .. i+depth on side HIP streams while set abstraction, flow embedding
 of batch i run on the main stream (the reference never batches or pipelines: one pair per call,
 /root/reference/deepclr/models/base.py:118-120, scripts/inference.py:100-104).
 """
-import os
 from collections import deque
 from typing import Deque, Iterable, Iterator, Optional, Tuple
 
@@ -39,8 +38,7 @@ class PipelinedForward:
         self.group = group
         self._ahead = ahead
         self._waiting = []                          # batches collected for the next grouped launch
-        prio = int(os.environ.get('DCLR_SIDE_PRIORITY', '0'))
-        self._streams = [torch.cuda.Stream(priority=prio) for _ in range(depth)]
+        self._streams = [torch.cuda.Stream() for _ in range(depth)]
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
 
