@@ -328,10 +328,12 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     __shared__ FpsCand cand[2][16];                        // per-wave candidate payload, by round parity
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
-    extern __shared__ uint32_t dyn_lds[];                  // BINS counters, NP sorted keys, max(NP, m) scratch/picked
+    // BINS counters (u32), NP sorted indices / tie keys (u16: n <= 16384 and keys < 0xFFFF), then NP cell ids (u16)
+    // whose storage `picked` (i32 x m) takes over after the sort: 16 + 32 + 32 KB at NP = 16384
+    extern __shared__ uint32_t dyn_lds[];
     uint32_t *hist = dyn_lds;
-    uint32_t *sbuf = dyn_lds + BINS;
-    int32_t *picked = reinterpret_cast<int32_t *>(dyn_lds + BINS + NP);   // shares storage with `cellof`
+    uint16_t *sbuf = reinterpret_cast<uint16_t *>(dyn_lds + BINS);
+    int32_t *picked = reinterpret_cast<int32_t *>(dyn_lds + BINS + NP / 2);   // shares storage with `cellof`
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     pts += (size_t)blockIdx.x * n * pstride;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     // ---- 2. counting sort by a 12-bit Morton cell (4 bits per axis, one common cell size). The sort
     //         only decides which wave owns which point; any order yields the same samples. -----------
     const float scale = ext > 0.f ? 15.999f / ext : 0.f;
-    uint32_t *cellof = sbuf + NP;                          // scratch list of cell ids, dead before `picked` is used
+    uint16_t *cellof = sbuf + NP;                          // scratch list of cell ids, dead before `picked` is used
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 mc |= (((q[0] >> bit) & 1u) << (3 * bit)) | (((q[1] >> bit) & 1u) << (3 * bit + 1)) |
                       (((q[2] >> bit) & 1u) << (3 * bit + 2));
             atomicAdd(&hist[mc], 1u);
-            cellof[k] = mc;
+            cellof[k] = (uint16_t)mc;
         }
     }
     __syncthreads();
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
-        if (k < n) sbuf[atomicAdd(&hist[cellof[k]], 1u)] = (uint32_t)k;
+        if (k < n) sbuf[atomicAdd(&hist[cellof[k]], 1u)] = (uint16_t)k;
     }
     __syncthreads();
     // ---- 3. this thread's points: wave w owns sorted positions [w*64*P, (w+1)*64*P); its P register
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     // right point on equal distances; groups and lanes are merged with an explicit key comparison.
     // The sorted keys go back to LDS (same positions, now in slot order): the hot loop never needs
     // them in registers, only the winner's key is fetched once per round.
-    uint32_t *skey = sbuf + wave * 64 * P + lane;          // this thread's key of slot jj: skey[jj * 64]
+    uint16_t *skey = sbuf + wave * 64 * P + lane;          // this thread's key of slot jj: skey[jj * 64]
     vec px, py, pz, td;
     float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};   // lane g: box of group g
     float gmaxv = 0.f;                                     // lane g: upper bound of group g's largest running minimum;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int jj = g * S + i;
-            skey[jj * 64] = tkg[i];                        // own positions only: no cross-thread hazard
+            skey[jj * 64] = (uint16_t)tkg[i];              // own positions only: no cross-thread hazard
             float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;   // -2: padding can never beat best = -1
             if (tkg[i] != 0xFFFFu) {
                 const uint32_t k = fps_tk1024_inv(tkg[i]);
@@ -982,7 +984,8 @@ template <int WGS, int P, int G>
 void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, float4 *group_pts,
                    float *group_box, hipStream_t s) {
     constexpr int NP = WGS * P;
-    const size_t lds = ((size_t)4096 + (size_t)NP + (size_t)(m > NP ? m : NP)) * sizeof(uint32_t);
+    const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
+    const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
     hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                        group_pts, group_box);
 }
