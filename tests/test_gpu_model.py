@@ -346,6 +346,16 @@ def test_pipelined_runner_matches_plain_forward():
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+    # results written straight into a caller's buffer (what bench.py hands to the all-gather)
+    runner = PipelinedForward(model, depth=2, ahead='knn', group=2)
+    slots = torch.zeros(len(batches), want[0].shape[0], want[0].shape[1], device=DEV)
+    for i, b in enumerate(batches):
+        y = runner.step(b, batches[i + 1:], out=slots[i])
+        assert y.data_ptr() == slots[i].data_ptr()
+    assert torch.equal(slots, torch.stack(want))
+    with pytest.raises(RuntimeError):
+        model.merge_rows(model.cloud_feature_rows(batches[0]), batches[0].shape[0] // 2,
+                         out=torch.zeros(3, 8, device=DEV))
 
 
 def test_sequence_mode_computes_each_frame_once_and_matches_pairwise_calls():
