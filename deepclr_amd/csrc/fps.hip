@@ -314,7 +314,7 @@ struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
 };
 
 // WGS threads, P points per thread (WGS * P = padded cloud size, a power of two), G groups per wave.
-template <int WGS, int P, int G>
+template <int WGS, int P, int G, bool MULTI>
 __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int m,
                                                          const float *__restrict__ pts,
                                                          float *__restrict__ temp,
@@ -326,6 +326,10 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     typedef typename VecOf<P>::type vec;
     __shared__ unsigned long long cell[3];                 // per-round 64-bit arg-max cells, rotated
     __shared__ FpsCand cand[2][16];                        // per-wave candidate payload, by round parity
+    __shared__ unsigned long long wpk[2][16];              // MULTI: per-wave packed candidate, by round parity
+    __shared__ uint32_t wru[2][16];                        // MULTI: per-wave runner-up (largest other running minimum)
+    __shared__ float plist[4][4];                          // MULTI: the samples accepted for the next round
+    __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
     // BINS counters (u32), NP sorted indices / tie keys (u16: n <= 16384 and keys < 0xFFFF), then NP cell ids (u16)
@@ -516,6 +520,225 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     unsigned long long acc_upd = 0, acc_bar = 0, acc_comb = 0, n_act = 0;
     unsigned long long dbg_box = 0, dbg_upd = 0, dbg_sel = 0, dbg_pub = 0, dbg_idle = 0, dbg_nact = 0;
 #endif
+    if constexpr (MULTI) {
+        // ---- several samples per barrier round -----------------------------------------------------------
+        // Sample r+1 is the point with the largest running minimum AFTER sample r has been applied. Let every
+        // wave w publish its best point c_w (value b_w, tie key) and its runner-up value u_w = the largest
+        // running minimum among its other points. With p1 the best candidate overall, the best candidate p2 of
+        // the OTHER waves is the next sample as well, provided (i) sqdist(p2, p1) >= td[p2] (its value does not
+        // change when p1 is applied) and (ii) td[p2] > u_w1 (nothing left in p1's wave can reach it; running
+        // minima only decrease). Every other point is already ordered behind p2: in p2's wave and in the
+        // remaining waves by the per-wave arg-max (ties by key), in p1's wave by (ii). The same argument admits
+        // p3 after p1, p2, and so on. All waves evaluate the test on the same 16 published entries, so they agree
+        // without another exchange; then each applies the accepted samples one after the other. The exchange
+        // (select, publish, barrier, combine) -- two thirds of a round -- is paid once per batch of samples.
+        constexpr int J = 3;
+        if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
+        __syncthreads();
+        float pcx[J] = {cx}, pcy[J] = {cy}, pcz[J] = {cz};
+        int np = 1;
+        uint32_t c_ru = 0u;
+        int sr = 0;
+#ifdef FPS_DEBUG
+        unsigned long long mu = 0, ms = 0, mb = 0, mc = 0, mt = 0;
+#endif
+        for (int r = 1; r < m;) {
+#ifdef FPS_DEBUG
+            unsigned long long q0, q1, q2, q3, q4;
+            FPS_STAMP(q0);
+#endif
+            uint32_t touched = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (j >= np) break;                                       // wave-uniform
+                const float sx = pcx[j], sy = pcy[j], sz = pcz[j];
+                const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], sx, sy, sz);
+                const uint32_t act = (uint32_t)__ballot(lbv < gmaxv);
+                if (act == 0) continue;                                   // wave-uniform
+                touched |= act;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (act & (1u << g)) {
+                        float best = -1.0f;
+                        int bjj = g * S;
+                        if constexpr (S % 2 == 0) {
+                            typedef float f2 __attribute__((ext_vector_type(2)));
+                            const f2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
+#pragma unroll
+                            for (int i = 0; i < S; i += 2) {
+                                const int jj = g * S + i;
+                                const f2 ax = {vec_get<P>(px, jj), vec_get<P>(px, jj + 1)};
+                                const f2 ay = {vec_get<P>(py, jj), vec_get<P>(py, jj + 1)};
+                                const f2 az = {vec_get<P>(pz, jj), vec_get<P>(pz, jj + 1)};
+                                const f2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
+                                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                                const f2 d = (xx + yy) + zz;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    float d2;
+                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d[h]), "v"(vec_get<P>(td, jj + h)));
+                                    vec_set<P>(td, jj + h, d2);
+                                    const bool gt = d2 > best;
+                                    bjj = gt ? jj + h : bjj;
+                                    best = gt ? d2 : best;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < S; ++i) {
+                                const int jj = g * S + i;
+                                const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), sx, sy, sz);
+                                float d2;
+                                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                                vec_set<P>(td, jj, d2);
+                                const bool gt = d2 > best;
+                                bjj = gt ? jj : bjj;
+                                best = gt ? d2 : best;
+                            }
+                        }
+                        gbest[g] = best; gjj[g] = bjj;
+                    }
+                }
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(q1);
+#endif
+            if (touched != 0) {
+                if ((sr & 7) == 1) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const float gm = __uint_as_float(dclr_wave_max_u32(gbest[g] < 0.f ? 0u : __float_as_uint(gbest[g])));
+                        gmaxv = lane == g ? gm : gmaxv;
+                    }
+                }
+                float lbest = gbest[0];
+#pragma unroll
+                for (int g = 1; g < G; ++g) lbest = fmaxf(lbest, gbest[g]);
+                const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
+                const float wmaxf = __uint_as_float(wmax);
+                int hits = 0, hjj = 0;
+#pragma unroll
+                for (int g = G - 1; g >= 0; --g) {
+                    const bool eq = gbest[g] == wmaxf;
+                    hits += eq ? 1 : 0;
+                    hjj = eq ? gjj[g] : hjj;
+                }
+                const uint64_t lanes_hit = __ballot(hits > 0);
+                int wl, wjj;
+                uint32_t wkey;
+                if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
+                    wl = __builtin_ctzll(lanes_hit);
+                    wjj = __builtin_amdgcn_readlane(hjj, wl);
+                    wkey = sbuf[wave * 64 * P + wjj * 64 + wl];
+                } else {
+                    uint32_t key = 0xFFFFFFFFu;
+                    int kjj = 0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        uint32_t kg = 0xFFFFu;
+                        if (gbest[g] == wmaxf) kg = skey[gjj[g] * 64];
+                        const bool take = gbest[g] == wmaxf && kg < key;
+                        key = take ? kg : key;
+                        kjj = take ? gjj[g] : kjj;
+                    }
+                    wkey = dclr_wave_min_u32(key);
+                    wl = __builtin_ctzll(__ballot(key == wkey));
+                    wjj = __builtin_amdgcn_readlane(kjj, wl);
+                }
+                c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - wkey) << 16) |
+                           (unsigned long long)wave;
+                c_k = (int32_t)fps_tk1024_inv(wkey);
+                c_x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
+                c_y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
+                c_z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
+                // runner-up of the wave: every other lane's best; in the winner's lane the other groups' bests
+                // and the other slots of the winner's (lane, group) cell
+                const int wcell = wjj / S;                            // wave-uniform
+                float other = -1.0f;
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const int jj = wcell * S + i;                     // wave-uniform register index
+                    const float v = vec_get<P>(td, jj);
+                    other = jj != wjj ? fmaxf(other, v) : other;
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) other = g != wcell ? fmaxf(other, gbest[g]) : other;
+                const float alt = lane == wl ? other : lbest;
+                c_ru = dclr_wave_max_u32(alt < 0.f ? 0u : __float_as_uint(alt));
+                fresh = 2;
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(q2);
+#endif
+            const int par = sr & 1;
+            if (lane == 0) {
+                if (fresh > 0) cand[par][wave] = FpsCand{c_k, c_x, c_y, c_z};
+                wpk[par][wave] = c_packed;
+                wru[par][wave] = c_ru;
+            }
+            fresh = fresh > 0 ? fresh - 1 : 0;
+            __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(q3);
+#endif
+            // wave 0 alone reads the 16 published entries (lane & 15 = wave) and derives the list of samples; the
+            // others wait at a second barrier and read the list (all 16 waves evaluating it redundantly cost
+            // more: four waves per SIMD competing for the same issue slots, ~1300 cycles per round)
+            if (wave == 0) {
+                const unsigned long long e = wpk[par][lane & 15];
+                const uint32_t e_ru = wru[par][lane & 15];
+                const FpsCand w = cand[par][lane & 15];
+                uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
+                uint32_t ru_acc[J];
+                float qx[J], qy[J], qz[J];
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    if (r + j >= m) break;                                    // uniform
+                    const uint32_t m_hi = dclr_row16_max_u32(e_hi);
+                    // the wave holding it: unique unless two waves tie on the value (then the key field decides)
+                    const uint32_t holders = (uint32_t)__ballot(e_hi == m_hi) & 0xFFFFu;
+                    int wid;
+                    if ((holders & (holders - 1)) == 0) wid = __builtin_ctz(holders);
+                    else wid = (int)(dclr_row16_max_u32(e_hi == m_hi ? e_lo : 0u) & 15u);
+                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.x), wid));
+                    const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.y), wid));
+                    const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.z), wid));
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < j; ++i) {
+                        const uint32_t dist = __float_as_uint(dclr_sqdist(x, y, z, qx[i], qy[i], qz[i]));
+                        ok = ok && m_hi > ru_acc[i] && dist >= m_hi;
+                    }
+                    if (!ok) break;
+                    qx[j] = x; qy[j] = y; qz[j] = z;
+                    ru_acc[j] = (uint32_t)__builtin_amdgcn_readlane((int)e_ru, wid);
+                    if (lane == 0) {
+                        picked[r + j] = __builtin_amdgcn_readlane(w.k, wid);
+                        plist[j][0] = x; plist[j][1] = y; plist[j][2] = z;
+                    }
+                    cnt = j + 1;
+                    const bool mine = (lane & 15) == wid;
+                    e_hi = mine ? 0u : e_hi;
+                    e_lo = mine ? 0u : e_lo;
+                }
+                if (lane == 0) plist_n = cnt;
+            }
+            __syncthreads();
+            np = plist_n;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { pcx[j] = plist[j][0]; pcy[j] = plist[j][1]; pcz[j] = plist[j][2]; }
+            r += np;
+            sr += 1;
+#ifdef FPS_DEBUG
+            FPS_STAMP(q4);
+            mu += q1 - q0; ms += q2 - q1; mb += q3 - q2; mc += q4 - q3; mt += touched != 0 ? 1 : 0;
+#endif
+        }
+#ifdef FPS_DEBUG
+        if (lane == 0 && blockIdx.x == 0) { fps_dbg[11] = (unsigned long long)sr; if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = ms; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; } }
+#endif
+    } else {
     int c3 = 1;                                                   // r % 3
     for (int r = 1; r < m; ++r) {
 #ifdef FPS_DEBUG
@@ -681,6 +904,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         fps_dbg[10] = dbg_nact;
     }
 #endif
+
+    }   // single-sample rounds
 
     __syncthreads();
     for (int i = t; i < m; i += WGS) idx[i] = picked[i];
@@ -986,8 +1211,13 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     constexpr int NP = WGS * P;
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
-    hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                       group_pts, group_box);
+    static const bool single = getenv("DCLR_FPS_SINGLE") != nullptr;          // A/B switch: one sample per barrier round
+    if (single)
+        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, false>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+                           group_pts, group_box);
+    else
+        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, true>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+                           group_pts, group_box);
 }
 
 // Spatial groups the pruned kernel forms (and can export): 16 waves x G groups of 64 * (P / G) points.
