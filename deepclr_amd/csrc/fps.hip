@@ -647,10 +647,13 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 }
                 c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - wkey) << 16) |
                            (unsigned long long)wave;
-                c_k = (int32_t)fps_tk1024_inv(wkey);
-                c_x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
-                c_y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
-                c_z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
+                // the winning lane stores the payload itself, for both parities: wave 0 finished reading the other
+                // parity's entries before the second barrier of the previous round
+                if (lane == wl) {
+                    const FpsCand c{(int32_t)fps_tk1024_inv(wkey), vec_get<P>(px, wjj), vec_get<P>(py, wjj), vec_get<P>(pz, wjj)};
+                    cand[0][wave] = c;
+                    cand[1][wave] = c;
+                }
                 // runner-up of the wave: every other lane's best; in the winner's lane the other groups' bests
                 // and the other slots of the winner's (lane, group) cell
                 const int wcell = wjj / S;                            // wave-uniform
@@ -665,18 +668,15 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 for (int g = 0; g < G; ++g) other = g != wcell ? fmaxf(other, gbest[g]) : other;
                 const float alt = lane == wl ? other : lbest;
                 c_ru = dclr_wave_max_u32(alt < 0.f ? 0u : __float_as_uint(alt));
-                fresh = 2;
             }
 #ifdef FPS_DEBUG
             FPS_STAMP(q2);
 #endif
             const int par = sr & 1;
             if (lane == 0) {
-                if (fresh > 0) cand[par][wave] = FpsCand{c_k, c_x, c_y, c_z};
                 wpk[par][wave] = c_packed;
                 wru[par][wave] = c_ru;
             }
-            fresh = fresh > 0 ? fresh - 1 : 0;
             __syncthreads();
 #ifdef FPS_DEBUG
             FPS_STAMP(q3);
