@@ -125,3 +125,45 @@ def test_fps_large_clouds_workspace_kernel_bit_exact(kind, b, n, m):
     got = ops.fps_clouds(x, m).cpu()
     assert torch.equal(got, want), 'first mismatch at {}'.format((got != want).nonzero()[:3].tolist())
     assert torch.equal(ops.furthest_point_sample(x, m).cpu(), want)
+
+
+# ---- randomised shapes (hypothesis): every kernel variant boundary gets crossed sooner or later -------------------
+from hypothesis import HealthCheck, given, settings, strategies as st      # noqa: E402
+
+_KINDS = st.sampled_from(['normal', 'kitti', 'dup', 'grid'])
+_SETTINGS = dict(max_examples=40, deadline=None, derandomize=True,
+                 suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+
+
+@settings(**_SETTINGS)
+@given(kind=_KINDS, b=st.integers(1, 3), n=st.integers(1, 40000), m=st.integers(1, 700), seed=st.integers(0, 999))
+def test_fps_bit_exact_random_shapes(kind, b, n, m, seed):
+    xyz = _cloud(kind, b, n, seed)
+    want = oracle.furthest_point_sample(xyz, m)
+    got = ops.fps_clouds(xyz.to(DEV), m).cpu()                        # register / pruned / paged kernels by n
+    assert torch.equal(got, want), (kind, b, n, m, (got != want).nonzero()[:3].tolist())
+
+
+@settings(**_SETTINGS)
+@given(kind=_KINDS, b=st.integers(1, 3), nx=st.integers(8, 3000), ny=st.integers(1, 400), k=st.integers(1, 40),
+       seed=st.integers(0, 999))
+def test_knn_bit_exact_random_shapes(kind, b, nx, ny, k, seed):
+    k = min(k, nx)
+    x = _cloud(kind, b, nx, seed).reshape(-1, 3)
+    y = _cloud(kind, b, ny, seed + 1).reshape(-1, 3)
+    bx, by = torch.arange(b).repeat_interleave(nx), torch.arange(b).repeat_interleave(ny)
+    want = oracle.knn(x, y, k, bx, by)
+    got = ops.knn(x.to(DEV), y.to(DEV), k, bx.to(DEV), by.to(DEV)).cpu()
+    assert torch.equal(got, want), (kind, b, nx, ny, k)
+
+
+@settings(**_SETTINGS)
+@given(kind=_KINDS, n=st.integers(64, 6000), m=st.integers(1, 300), radius=st.floats(0.05, 3.0), nsample=st.integers(1, 64),
+       seed=st.integers(0, 999))
+def test_ball_query_bit_exact_random_shapes(kind, n, m, radius, nsample, seed):
+    xyz = _cloud(kind, 2, n, seed)
+    fps = oracle.furthest_point_sample(xyz, min(m, n))
+    new_xyz = torch.gather(xyz, 1, fps.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    want = oracle.ball_query(radius, nsample, xyz, new_xyz)
+    got = ops.ball_query(radius, nsample, xyz.to(DEV), new_xyz.to(DEV)).cpu()
+    assert torch.equal(got, want), (kind, n, m, radius, nsample)
