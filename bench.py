@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """Throughput of the DeepCLR forward hot path on MI355X: scan-pairs/s (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One step = one forward pass of the whole hot path (FPS -> set abstraction -> kNN -> flow embedding ->
-pose head) over one batch of synthetic KITTI-sized pairs already resident in HBM: BASELINE.json
-configs[1], 8 pairs of 2 x 16384 points per GPU. Ranks own independent pairs (weak scaling, no
-data-path collective); the only exchange is an RCCL all-gather of the (8, 8) pose outputs per step.
-Rank 0 prints ONE JSON line. The CPU oracle is used only for the `cpu_baseline` leg and the pose
-check -- never inside the timed region.
+pose head) over one batch of synthetic pairs already resident in HBM. The headline workload (`--config c2`,
+the default) is BASELINE.json configs[1]: 8 KITTI-sized pairs of 2 x 16384 points per GPU; `c4` (256 ModelNet
+pairs of 2 x 2048 points) and `c5` (4 pairs of 2 x 65536 points) are BASELINE.json configs[3] / configs[4] and
+print the same JSON schema. Ranks own independent pairs (weak scaling, no data-path collective); the only
+exchange is an RCCL all-gather of the pose outputs.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one fresh child process
+per GPU, before this process has touched the GPU) and relays rank 0's JSON line. Rank 0 prints ONE JSON line.
+The CPU oracle is used only for the `cpu_baseline` leg and the pose check -- never inside the timed region.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +32,7 @@ import time
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import numpy as np                                          # noqa: E402
-import torch                                                # noqa: E402
+import torch                                                # noqa: E402  (importing torch does not touch the GPU)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -36,14 +43,94 @@ from deepclr_amd.labels import LabelType                    # noqa: E402
 from deepclr_amd.models import build_model                  # noqa: E402
 from deepclr_amd.pipeline import PipelinedForward, PipelinedSequence           # noqa: E402
 
-PAIRS_PER_GPU = 8
-POINTS = 16384
+# BASELINE.json configs that fit one GPU. depth / group: side streams and batches per sampling launch of the
+# pipelined runner (the sampler is one workgroup per cloud: c2 needs grouped launches to have enough clouds in
+# flight, c4 already brings 512 clouds per batch).
+CONFIGS = {
+    'c2': {'kind': 'kitti', 'pairs': 8, 'points': 16384, 'depth': 3, 'group': 4, 'steps': 200, 'warmup': 20,
+           'baseline': 'BASELINE.json configs[1]'},
+    'c4': {'kind': 'modelnet', 'pairs': 256, 'points': 2048, 'depth': 2, 'group': 1, 'steps': 40, 'warmup': 5,
+           'baseline': 'BASELINE.json configs[3]'},
+    'c5': {'kind': 'kitti', 'pairs': 4, 'points': 65536, 'depth': 3, 'group': 2, 'steps': 100, 'warmup': 10,
+           'baseline': 'BASELINE.json configs[4]'},
+}
+PAIRS_PER_GPU = CONFIGS['c2']['pairs']
+POINTS = CONFIGS['c2']['points']
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+FP32_VECTOR_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: peak FP32 (vector)
 F16_MATRIX_PEAK_TFLOPS = 2516.6      # MI355X_MICROARCH.md: dense f16/bf16 MFMA = 16 x the f32 matrix rate (~2.5 PF)
 SPLIT_PRODUCTS = 3                   # f16 MFMAs per f32-accurate product on the split path (csrc/mma16f.h)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak
+FPS_FLOP_PER_EVAL = 9                # 3 sub, 3 mul, 2 add, 1 min per (point, sample) distance update
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: PMC traffic figures collected offline are attached to a bench line only
+    when they were measured on exactly these kernels (profiles/collect_traffic.py stamps the same hash)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'deepclr_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            with open(os.path.join(csrc, name), 'rb') as fh:
+                h.update(name.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` (what the driver runs) -> N fresh children, one per GPU
+# ----------------------------------------------------------------------------------------------------------
+def rank_environments(n: int, port: int, base_env=None):
+    """The N child environments torch.distributed.run would build for one node."""
+    envs = []
+    for rank in range(n):
+        env = dict(os.environ if base_env is None else base_env)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DCLR_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('GPU_MAX_HW_QUEUES', '8')
+        envs.append(env)
+    return envs
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Start one child per GPU BEFORE this process makes any GPU call (a process that has initialised the GPU
+    must never exec or fork GPU children). Rank 0's stdout is relayed; returns the worst exit code."""
+    envs = rank_environments(n, free_port())
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for rank, env in enumerate(envs):
+        out = subprocess.PIPE if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(cmd, env=env, stdout=out, text=(rank == 0)))
+    line_seen = False
+    for line in procs[0].stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        line_seen = line_seen or line.lstrip().startswith('{')
+    codes = []
+    deadline = time.time() + 120
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()                                        # the exact child started here, nothing else
+            codes.append(p.wait())
+    bad = [c for c in codes if c != 0]
+    if bad or not line_seen:
+        sys.stderr.write('bench.py: rank exit codes {} (json line seen: {})\n'.format(codes, line_seen))
+        return bad[0] if bad else 1
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------
+# per-kernel HIP events
+# ----------------------------------------------------------------------------------------------------------
 class LaunchTimer:
     """HIP events around every library launch, on the stream the kernel is enqueued on."""
 
@@ -76,7 +163,7 @@ class LaunchTimer:
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
 
-    def merge_events(self, rows, n_fc=3):
+    def merge_events(self, pairs, npoint, k, n_fc=3):
         """Raw HIP events for the stages of one dclr_merge_forward call (the dense stages are one foreign call;
         the library records these between its launches, on the launch stream)."""
         if self.step % self.SAMPLE_EVERY != 0:
@@ -91,7 +178,10 @@ class LaunchTimer:
             if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
                 return None
             arr[i] = ev.value
-        names = ['linear_pair[2x%dx128x64]' % rows, None, 'knn_rows', 'flow_embedding', 'head_conv_fused'] + ['fc'] * n_fc
+        rows = pairs * npoint
+        names = ['linear_pair[2x%dx128x64]' % rows, None, 'knn_rows[%dx%dx%d]' % (pairs, npoint, k),
+                 'flow_embedding[%dx%dx%d]' % (pairs, npoint, k), 'head_conv_fused[%dx%d]' % (pairs, npoint)]
+        names += ['fc[%d]' % pairs] * n_fc
         on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
         self.raw.append((arr, names, on_main))
         return arr
@@ -116,35 +206,73 @@ class LaunchTimer:
                 for k, v in acc.items()}
 
 
-def algorithmic_work(name: str, cfg: dict, pairs: int, n_points: int, clouds: int):
-    """(bound, units) per launch: flops for the MFMA kernels, bytes for the memory-shaped ones.
-    Figures are stated per scan pair in DESIGN.md section 'Kernels and rooflines'."""
+def _dims(name: str):
+    return [int(v) for v in name[name.index('[') + 1:-1].split('x')]
+
+
+def kernel_base(name: str) -> str:
+    return name.split('[')[0]
+
+
+def algorithmic_work(name: str, cfg: dict):
+    """(bound, units per launch, extra) for a timed span. The span name carries the launch's own sizes
+    (`fps_clouds[64x16384]` = 64 clouds of 16384 points in ONE launch -- a grouped sampling launch covers
+    group x 2B clouds), so the figure is per launch by construction. flops for the MFMA kernels, bytes for the
+    memory-shaped ones; the sampler is a latency chain and is priced in distance evaluations.
+    Per-pair figures are stated in DESIGN.md section 4."""
     sa = cfg['params']['cloud_features']['params']
-    npoint, k = sa['npoint'][0], cfg['params']['merge']['params']['k']
+    npoint = sa['npoint'][0]
     c = cfg['input_dim']
-    if name.startswith('linear_pair'):
-        m, n, kk = (int(v) for v in name[name.index('[') + 3:-1].split('x'))
-        return 'mfma', 4.0 * m * n * kk
-    if name.startswith('linear'):
-        m, n, kk = (int(v) for v in name[name.index('[') + 1:-1].split('x'))
-        return 'mfma', 2.0 * m * n * kk
-    if name == 'head_conv_fused':
-        out = cfg['params']['output']['params']['mlp']
-        dims = [264] + list(out)
-        return 'mfma', 2.0 * pairs * npoint * sum(a * b for a, b in zip(dims[:-1], dims[1:]))
-    if name == 'flow_embedding':
-        rows = pairs * npoint * k
-        return 'mfma', 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5
-    if name == 'fps_clouds':        # reads every cloud once, writes the indices
-        return 'hbm', clouds * (n_points * c * 4 + npoint * 4)
-    if name == 'sa_msg_fused':      # reads every cloud once + index list, writes 68-float rows
-        return 'hbm', clouds * (n_points * c * 4 + npoint * 4 + npoint * 68 * 4)
-    if name == 'knn_rows':
-        return 'hbm', pairs * npoint * (2 * 68 * 4 + k * 4)
-    return 'hbm', 0.0
+    base = kernel_base(name)
+    if base == 'linear_pair':
+        _, m, n, kk = _dims(name)
+        return 'mfma', 4.0 * m * n * kk, {}
+    if base in ('linear', 'linear+colmax'):
+        m, n, kk = _dims(name)
+        return 'mfma', 2.0 * m * n * kk, {}
+    if base == 'head_conv_fused':
+        pairs, pts = _dims(name)
+        dims = [264] + list(cfg['params']['output']['params']['mlp'])
+        return 'mfma', 2.0 * pairs * pts * sum(a * b for a, b in zip(dims[:-1], dims[1:])), {}
+    if base == 'flow_embedding':
+        pairs, pts, k = _dims(name)
+        rows = pairs * pts * k
+        return 'mfma', 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5, {}
+    if base == 'fps_clouds':        # serial chain: (npoint - 1) dependent samples per cloud, each a pass over the cloud
+        clouds, n = _dims(name)
+        evals = float(clouds) * (npoint - 1) * n
+        return 'valu-latency', evals * FPS_FLOP_PER_EVAL, {'clouds_per_launch': clouds, 'dist_evals': evals,
+                                                           'samples_per_cloud': npoint - 1}
+    if base == 'sa_msg_fused':      # reads every cloud once + index list, writes 68-float rows
+        clouds, n = _dims(name)
+        return 'hbm', float(clouds) * (n * c * 4 + npoint * 4 + npoint * 68 * 4), {'clouds_per_launch': clouds}
+    if base == 'knn_rows':
+        pairs, pts, k = _dims(name)
+        return 'hbm', float(pairs) * pts * (2 * 68 * 4 + k * 4), {}
+    if base == 'fc':                # weights dominate: (n, k) f32 read once, m rows in and out
+        (m,) = _dims(name)
+        lin = cfg['params']['output']['params']['linear']
+        dims = list(lin) + [8]
+        per_layer = [(a * b + m * a + m * b) * 4.0 for a, b in zip(dims[:-1], dims[1:])]
+        return 'hbm', sum(per_layer) / len(per_layer), {'note': 'mean over the %d fully connected launches' % len(per_layer)}
+    return 'hbm', 0.0, {}
 
 
-def cpu_baseline(cfg, sd, budget_s: float = 15.0):
+def load_traffic():
+    """HBM bytes per launch from the PMC passes kept under profiles/ (a counter run cannot share a process with
+    the timed region). Returned only if they were collected on the kernels this run uses."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return {}, 'no profiles/pmc_traffic.json'
+    if doc.get('kernel_source_hash') != kernel_source_hash():
+        return {}, 'profiles/pmc_traffic.json was collected on other kernel sources (commit {}): not attached'.format(
+            doc.get('commit', '?'))
+    return doc.get('configs', {}), 'profiles/pmc_traffic.json @ commit {}'.format(doc.get('commit', '?'))
+
+
+def cpu_baseline(cfg, sd, kind: str, points: int, budget_s: float = 15.0):
     """The oracle (a port: the reference has no CPU path) on this host's cores."""
     import oracle
     orc = oracle.build_oracle_model(cfg, sd)
@@ -152,45 +280,84 @@ def cpu_baseline(cfg, sd, budget_s: float = 15.0):
     threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     oracle.primitives.set_threads(threads)
-    x = torch.from_numpy(synthetic.make_batch('kitti', 1, POINTS))
+    x = torch.from_numpy(synthetic.make_batch(kind, 1, points))
     orc(x)                                           # warm-up (library init, allocator)
     done, t0 = 0, time.perf_counter()
     while True:
-        orc(torch.from_numpy(synthetic.make_batch('kitti', 1, POINTS, first_pair=done + 1)))
+        orc(torch.from_numpy(synthetic.make_batch(kind, 1, points, first_pair=done + 1)))
         done += 1
         elapsed = time.perf_counter() - t0
         if elapsed > budget_s or done >= 64:
             break
     return {'value': done / elapsed, 'unit': 'scan-pairs/s', 'cores': threads, 'kind': 'port',
             'sample': '{} pairs of 2x{} points, batch 1, fp32, {:.1f} s wall; torch intra-op + OpenMP threads = {}'
-                      .format(done, POINTS, elapsed, threads)}
+                      .format(done, points, elapsed, threads)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', default='c2', choices=sorted(CONFIGS),
+                    help='workload: c2 = BASELINE.json configs[1] (headline), c4 = configs[3], c5 = configs[4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-launch-timer', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--no-overlap', action='store_true', help='run sampling in line instead of batches ahead')
-    ap.add_argument('--depth', type=int, default=3, help='batches whose sampling runs ahead on side streams')
+    ap.add_argument('--depth', type=int, default=None, help='batches whose sampling runs ahead on side streams')
     ap.add_argument('--sequence', action='store_true',
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
-    ap.add_argument('--group', type=int, default=4, help='batches sampled by one launch on a side stream')
+    ap.add_argument('--group', type=int, default=None, help='batches sampled by one launch on a side stream')
     ap.add_argument('--gather-every', type=int, default=4, help='steps whose outputs share one all-gather (N > 1)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    wl = CONFIGS[args.config]
+    for key in ('steps', 'warmup', 'depth', 'group'):
+        if getattr(args, key) is None:
+            setattr(args, key, wl[key])
+    return args
 
+
+class OutputGather:
+    """Pose outputs of `gather_every` consecutive steps share one all-gather: the steps write side by side into
+    one send buffer (bigger, fewer collectives; every call makes the main stream wait for RCCL's stream)."""
+
+    def __init__(self, dist, world: int, gather_every: int, pairs: int, dim: int, device):
+        self.dist, self.every, self.pairs = dist, max(1, gather_every), pairs
+        self.send = torch.zeros(self.every, pairs, dim, device=device)
+        self.gathered = torch.empty(world * self.every * pairs, dim, device=device)
+        self.filled = 0
+        self.collectives = 0
+
+    def slot(self):
+        return self.send[self.filled]
+
+    def put(self, y):
+        """The step's outputs are in slot() already (written in place) or handed in as `y`."""
+        if y is not None:
+            self.send[self.filled, :y.shape[0]].copy_(y[-self.pairs:] if y.shape[0] > self.pairs else y)
+        self.filled += 1
+        if self.filled == self.every:
+            self.flush()
+
+    def flush(self):
+        if self.filled:
+            self.dist.all_gather_into_tensor(self.gathered, self.send.view(-1, self.send.shape[-1]))
+            self.collectives += 1
+            self.filled = 0
+
+
+def run(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={} (launch N>1 through torch.distributed.run)'
-                         .format(args.gpus, world))
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    wl = CONFIGS[args.config]
+    kind, pairs_cfg, points = wl['kind'], wl['pairs'], wl['points']
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -198,17 +365,17 @@ def main():
     if use_dist:
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
-            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29517', RANK='0', WORLD_SIZE='1')
+            os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1')
         dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
 
-    cfg = synthetic.model_cfg('kitti')
+    cfg = synthetic.model_cfg(kind)
     sd = synthetic.random_state_dict(cfg, seed=0)
     model = build_model(model_config_from_dict(cfg))
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    x = torch.from_numpy(synthetic.make_batch('kitti', PAIRS_PER_GPU, POINTS, first_pair=rank * PAIRS_PER_GPU)).to(dev)
-    
-    pairs_per_step = PAIRS_PER_GPU
+    x = torch.from_numpy(synthetic.make_batch(kind, pairs_cfg, points, first_pair=rank * pairs_cfg)).to(dev)
+
+    pairs_per_step = pairs_cfg
     if args.sequence:
         if args.no_overlap:
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
@@ -224,36 +391,28 @@ def main():
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
-    # all-gather once per GATHER_EVERY steps: the steps' outputs are written side by side into one send buffer
-    # (bigger, fewer collectives; every call makes the main stream wait for RCCL's stream)
-    gather_every = max(1, args.gather_every)
-    send = torch.zeros(gather_every, pairs_per_step, 8, device=dev) if use_dist else None
-    gathered = torch.empty(world * gather_every * pairs_per_step, 8, device=dev) if use_dist else None
-    counter = [0]
-
-    def flush():
-        dist.all_gather_into_tensor(gathered, send.view(-1, 8))
-        counter[0] = 0
+    gather = OutputGather(dist, world, args.gather_every, pairs_per_step, model.label_dim, dev) if use_dist else None
+    ranks_seen = [0]
+    if use_dist:                             # proof that the collective spans `world` ranks
+        mine = torch.tensor([rank], device=dev, dtype=torch.int32)
+        seen = torch.empty(world, device=dev, dtype=torch.int32)
+        dist.all_gather_into_tensor(seen, mine)
+        ranks_seen = [int(v) for v in seen.cpu()]
 
     def step():
-        slot = send[counter[0]] if use_dist and runner is not None and not args.sequence else None
+        in_place = gather is not None and runner is not None and not args.sequence
         if runner is not None:
-            y = runner.step(x, upcoming=[x], out=slot)   # sampling of later batches overlaps the stages of this one
+            y = runner.step(x, upcoming=[x], out=gather.slot() if in_place else None)
         else:
             with torch.no_grad():
                 y, _, _ = model(x)
-        if use_dist:
-            if slot is None:
-                send[counter[0], :y.shape[0]].copy_(y[-pairs_per_step:] if y.shape[0] > pairs_per_step else y)
-            counter[0] += 1
-            if counter[0] == gather_every:
-                flush()
+        if gather is not None:
+            gather.put(None if in_place else y)
         return y
 
     def fence():
-        if use_dist:
-            if counter[0]:
-                flush()
+        if gather is not None:
+            gather.flush()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -277,13 +436,17 @@ def main():
         solo = LaunchTimer(sample_every=1)
         ops.TIMER = solo
         with torch.no_grad():
+            xs = torch.cat([x] * args.group) if (args.group > 1 and not args.sequence and runner is not None) else x
             for _ in range(6):
                 if args.sequence:
                     f_rows = model.cloud_feature_rows(x)
                     rows, pairs, _ = model.sequence_rows(f_rows, x.shape[0], f_rows[-model.npoint:])
                     model.merge_rows(rows, pairs)
                 else:
-                    model(x)
+                    # the sampling stages at the launch size of the timed region (group x 2B clouds), the dense
+                    # stages per batch
+                    f_all = model.cloud_feature_rows(xs)
+                    model.merge_rows(f_all[:x.shape[0] * model.npoint], x.shape[0] // 2)
         torch.cuda.synchronize()
         ops.TIMER = None
         alone = solo.summary()
@@ -292,86 +455,107 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = None
     if rank == 0:
         pairs_total = world * pairs_per_step * args.steps
-        roofline, kernels = None, None
-        rooflines = None
+        roofline, kernels, rooflines = None, None, None
+        traffic_all, traffic_src = load_traffic()
+        traffic = traffic_all.get(args.config, {})
         if timer is not None:
             kernels = timer.summary()
             sampled_steps = len(range(0, args.steps, LaunchTimer.SAMPLE_EVERY))
 
-            traffic = {}
-            try:        # HBM bytes per launch from the PMC passes kept under profiles/ (collected offline: a
-                        # counter run cannot share a process with the timed region)
-                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as fh:
-                    traffic = {k: v['bytes_per_launch_raw'] for k, v in json.load(fh)['kernels'].items()}
-            except (OSError, KeyError, ValueError):
-                pass
-
             def roof(name):
-                bound, units = algorithmic_work(name, cfg, pairs_per_step, POINTS, x.shape[0])
+                bound, units, extra = algorithmic_work(name, cfg)
                 sec = kernels[name]['avg_us'] * 1e-6
                 basis = None
                 if bound == 'mfma':
                     # algorithmic (f32-equivalent) FLOP of the layer shapes; the fused flow / head kernels spend
                     # SPLIT_PRODUCTS f16 MFMAs per product, so their ceiling is the f16 dense peak / SPLIT_PRODUCTS
-                    split = ops.PRECISION == 'f16x2' and name in ('flow_embedding', 'head_conv_fused')
+                    split = ops.PRECISION == 'f16x2' and kernel_base(name) in ('flow_embedding', 'head_conv_fused')
                     peak = F16_MATRIX_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MATRIX_PEAK_TFLOPS
                     basis = ('f16 dense MFMA peak / 3 instructions per f32-accurate product' if split
                              else 'f32 MFMA peak')
                     achieved, unit = units / sec / 1e12, 'TFLOP/s'
+                elif bound == 'valu-latency':
+                    peak, unit, achieved = FP32_VECTOR_PEAK_TFLOPS, 'TFLOP/s', units / sec / 1e12
+                    basis = ('serial chain, no roofline applies: unpruned distance evaluations x {} FLOP against the '
+                             'f32 vector peak, for scale only').format(FPS_FLOP_PER_EVAL)
+                    extra = dict(extra, sample_rounds_per_s_per_cloud=extra['samples_per_cloud'] / sec,
+                                 sample_rounds_per_s=extra['samples_per_cloud'] * extra['clouds_per_launch'] / sec,
+                                 dist_evals_per_s=extra['dist_evals'] / sec,
+                                 us_per_sample=1e6 * sec / extra['samples_per_cloud'])
                 else:
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
                 solo_us = alone[name]['avg_us'] if alone and name in alone else None
-                return {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'peak_basis': basis,
-                        'unit': unit, 'frac': achieved / peak, 'traffic': traffic.get(name), 'avg_us': kernels[name]['avg_us'],
-                        'alone_us': solo_us,
-                        'frac_alone': None if solo_us is None else achieved / peak * kernels[name]['avg_us'] / solo_us,
-                        'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
-                        'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
+                tr = traffic.get(kernel_base(name))
+                out = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'peak_basis': basis,
+                       'unit': unit, 'frac': achieved / peak,
+                       'traffic': None if tr is None else tr.get('bytes_per_launch'),
+                       'avg_us': kernels[name]['avg_us'], 'alone_us': solo_us,
+                       'frac_alone': None if solo_us is None else achieved / peak * kernels[name]['avg_us'] / solo_us,
+                       'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
+                       'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
+                out.update(extra)
+                return out
 
             # dominant kernel = largest total time on the stream that bounds the step (the main one);
             # the side-stream sampler is latency-bound by construction and listed in `rooflines`
             main = [k for k in kernels if kernels[k]['main_stream']] or list(kernels)
             roofline = roof(max(main, key=lambda k: kernels[k]['total_ms']))
-            rooflines = [roof(k) for k in sorted(kernels, key=lambda k: -kernels[k]['total_ms'])[:6]]
-        # pose check of the last step's first pair against the oracle (outside the timed region)
+            rooflines = [roof(k) for k in sorted(kernels, key=lambda k: -kernels[k]['total_ms'])[:8]]
         result = {
-            'metric': 'scan-pairs/sec (2x16384 pts)', 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
+            'metric': 'scan-pairs/sec (2x{} pts)'.format(points), 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (matrix products: f16 hi/lo split operands, f32 accumulate)' if ops.PRECISION == 'f16x2' else 'f32', 'data': 'synthetic',
-            'config': {'workload': ('odometry chunks of {} consecutive KITTI-sized frames (16384 pts x 4 ch) = {} pairs'
+            'config': {'workload': ('odometry chunks of {0} consecutive {3}-like frames ({4} pts x {5} ch) = {1} pairs'
                                     '/GPU/step, each frame sampled once; NOT the BASELINE metric'
                                     if args.sequence else
-                                    'KITTI-sized scan pairs, 2x16384 pts x 4 ch, {1} pairs/GPU/step '
-                                    '(BASELINE.json configs[1])').format(x.shape[0], pairs_per_step)
-                                   + '; kitti_00-06 architecture, seeded random weights',
-                       'pairs_per_gpu': pairs_per_step, 'points_per_cloud': POINTS, 'parallelism': 'dp%d' % world,
+                                    '{3}-like scan pairs, 2x{4} pts x {5} ch, {1} pairs/GPU/step ({2})')
+                                   .format(x.shape[0], pairs_per_step, wl['baseline'], kind, points, x.shape[2])
+                                   + '; {} architecture, seeded random weights'.format(
+                                       'kitti_00-06' if kind == 'kitti' else 'modelnet40'),
+                       'id': args.config, 'pairs_per_gpu': pairs_per_step, 'points_per_cloud': points,
+                       'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
                        'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
                                                                 args.group, 'ahead': args.ahead}},
+            'ranks_seen': ranks_seen,
+            'collectives': None if gather is None else {'all_gathers': gather.collectives, 'steps_per_all_gather': gather.every,
+                                                         'bytes_per_rank': int(gather.send.numel() * 4)},
             'roofline': roofline,
         }
         if rooflines is not None:
             result['rooflines'] = rooflines
+            result['traffic_source'] = traffic_src
         if kernels is not None:
             result['kernels_us'] = {k: round(v['avg_us'], 1) for k, v in sorted(kernels.items())}
         if world == 1 and not args.no_cpu_baseline:
+            # pose check of the last step's first pair against the oracle (outside the timed region)
             import oracle
             from oracle import labels as olabels
-            first = [0, 1] if args.sequence else [0, PAIRS_PER_GPU]          # clouds of output row `row`
+            first = [0, 1] if args.sequence else [0, pairs_cfg]          # clouds of output row `row`
             row = 1 if args.sequence else 0
             y_ref = oracle.build_oracle_model(cfg, sd)(x[first].cpu())
             lt = LabelType.POSE3D_DUAL_QUAT
             result['pose_delta_vs_oracle'] = float(np.abs(lt.to_matrix(y[row].cpu().numpy())
                                                           - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max())
-            result['cpu_baseline'] = cpu_baseline(cfg, sd)
+            result['cpu_baseline'] = cpu_baseline(cfg, sd, kind, points)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # launched as `python bench.py --gpus N`: become the launcher (no GPU call has been made in this process)
+        raise SystemExit(spawn_ranks(args.gpus, argv))
+    run(args)
 
 
 if __name__ == '__main__':

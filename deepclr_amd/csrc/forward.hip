@@ -44,8 +44,11 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     if (rc != DCLR_OK) return rc;
     mark();
     const int n_last = a->head_n[a->n_head_layers - 1];
-    if (hipMemsetAsync(a->colmax, 0, (size_t)a->pairs * n_last * sizeof(float), st) != hipSuccess)
-        return dclr_launch_status();
+    const hipError_t ms = hipMemsetAsync(a->colmax, 0, (size_t)a->pairs * n_last * sizeof(float), st);
+    if (ms != hipSuccess) {
+        (void)hipGetLastError();                            // consume the sticky copy; the code below carries the error
+        return -(1000 + (int)ms);
+    }
     if (a->precision == 1)
         rc = dclr_head_conv_fused_f16(rows, a->n_head_layers, a->head_k_in, a->head_k, a->head_n, a->head_w, a->head_b,
                                       a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);

@@ -116,15 +116,33 @@ class LinearMultiLayer(_Stack):
 
 
 class PackedCache:
-    """Re-derive kernel-side weight buffers only when a parameter changed (load_state_dict, .to())."""
+    """Re-derive kernel-side weight buffers only when a parameter changed (load_state_dict, .to()).
+
+    The pack kernels run on the stream of whoever asks first; any OTHER stream that later asks for the same
+    buffers first waits for the event recorded behind them (the pipelined runner reads them from several side
+    streams at once, and a fresh model's first use may well be on one of those)."""
 
     def __init__(self):
         self._key = None
         self._value = None
+        self._event = None
+        self._stream = None
 
     def get(self, params, build):
         key = tuple((p.device, p.data_ptr(), p._version) for p in params)
         if key != self._key:
             self._value = build()
             self._key = key
+            self._event, self._stream = None, None
+            if params and params[0].is_cuda:
+                self._stream = torch.cuda.current_stream(params[0].device).cuda_stream
+                self._event = torch.cuda.Event()
+                self._event.record()
+        elif self._event is not None:
+            if self._event.query():
+                self._event = None                              # packing finished: visible to every stream
+            else:
+                cur = torch.cuda.current_stream()
+                if cur.cuda_stream != self._stream:
+                    cur.wait_event(self._event)
         return self._value

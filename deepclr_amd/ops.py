@@ -126,10 +126,10 @@ def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
     need = lib.load().dclr_fps_workspace_bytes(b, n)
     if need > 0 and npoint * 4 <= 32 * 1024:
         ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device)
-        _call('dclr_fps_clouds_ws', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+        _call('dclr_fps_clouds_ws', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), ws.data_ptr(),
               need, lib.stream_ptr())
         return idx
-    _call('dclr_fps_clouds', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr())
+    _call('dclr_fps_clouds', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -152,7 +152,7 @@ def fps_clouds_grouped(clouds: torch.Tensor, npoint: int):
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
     gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
     gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
-    _call('dclr_fps_clouds_grouped', 'fps_clouds', b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
+    _call('dclr_fps_clouds_grouped', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
           gbox.data_ptr(), lib.stream_ptr())
     return idx, gpts, gbox
 
@@ -178,7 +178,7 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
-    _call('dclr_sa_msg_fused', 'sa_msg_fused', b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
+    _call('dclr_sa_msg_fused', 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
                                            ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
                                            ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
           None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
@@ -259,7 +259,7 @@ def head_conv_fused(x: torch.Tensor, layers, groups: int) -> torch.Tensor:
     w_h = (ctypes.c_void_p * nl)(*[l[0].data_ptr() for l in layers])
     b_h = (ctypes.c_void_p * nl)(*[l[1].data_ptr() for l in layers])
     out = torch.zeros(groups, layers[-1][2], dtype=torch.float32, device=x.device)
-    _call('dclr_head_conv_fused', 'head_conv_fused', m, nl, ctypes.cast(k_h, ctypes.c_void_p), ctypes.cast(n_h, ctypes.c_void_p),
+    _call('dclr_head_conv_fused', 'head_conv_fused[%dx%d]' % (groups, m // groups), m, nl, ctypes.cast(k_h, ctypes.c_void_p), ctypes.cast(n_h, ctypes.c_void_p),
           ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p), x.data_ptr(), ldx, out.data_ptr(),
           m // groups, lib.stream_ptr())
     return out
@@ -288,7 +288,7 @@ def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torc
     w_h = (ctypes.c_void_p * nl)(*[l[0].data_ptr() for l in layers])
     b_h = (ctypes.c_void_p * nl)(*[l[1].data_ptr() for l in layers])
     out = torch.zeros(groups, layers[-1][2], dtype=torch.float32, device=x.device)
-    _call('dclr_head_conv_fused_f16', 'head_conv_fused', m, nl, int(k_in), ctypes.cast(k_h, ctypes.c_void_p),
+    _call('dclr_head_conv_fused_f16', 'head_conv_fused[%dx%d]' % (groups, m // groups), m, nl, int(k_in), ctypes.cast(k_h, ctypes.c_void_p),
           ctypes.cast(n_h, ctypes.c_void_p), ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p),
           x.data_ptr(), ldx, out.data_ptr(), m // groups, lib.stream_ptr())
     return out
@@ -299,7 +299,7 @@ def flow_embedding_fused_f16(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: to
                              w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
     pairs, npoint, k = knn_idx.shape
     e = torch.empty(pairs * npoint, E_STRIDE, dtype=torch.float32, device=f_rows.device)
-    _call('dclr_flow_embedding_fused_f16', 'flow_embedding', pairs, npoint, k, float(radius), f_rows.data_ptr(),
+    _call('dclr_flow_embedding_fused_f16', 'flow_embedding[%dx%dx%d]' % (pairs, npoint, k), pairs, npoint, k, float(radius), f_rows.data_ptr(),
           knn_idx.data_ptr(), pt.data_ptr(), ps.data_ptr(), w1a.data_ptr(), b1.data_ptr(), w2p.data_ptr(),
           b2.data_ptr(), w3p.data_ptr(), b3.data_ptr(), e.data_ptr(), lib.stream_ptr())
     return e
@@ -308,7 +308,7 @@ def flow_embedding_fused_f16(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: to
 def knn_rows(f_rows: torch.Tensor, pairs: int, npoint: int, k: int) -> torch.Tensor:
     f_rows = lib.dev_f32(f_rows, 'f_rows')
     idx = torch.empty(pairs, npoint, k, dtype=torch.int32, device=f_rows.device)
-    _call('dclr_knn_rows', 'knn_rows', pairs, npoint, k, f_rows.data_ptr(), idx.data_ptr(), lib.stream_ptr())
+    _call('dclr_knn_rows', 'knn_rows[%dx%dx%d]' % (pairs, npoint, k), pairs, npoint, k, f_rows.data_ptr(), idx.data_ptr(), lib.stream_ptr())
     return idx
 
 
@@ -317,7 +317,7 @@ def flow_embedding_fused(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.
                          w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
     pairs, npoint, k = knn_idx.shape
     e = torch.empty(pairs * npoint, E_STRIDE, dtype=torch.float32, device=f_rows.device)
-    _call('dclr_flow_embedding_fused', 'flow_embedding', pairs, npoint, k, float(radius), f_rows.data_ptr(),
+    _call('dclr_flow_embedding_fused', 'flow_embedding[%dx%dx%d]' % (pairs, npoint, k), pairs, npoint, k, float(radius), f_rows.data_ptr(),
                                                    knn_idx.data_ptr(), pt.data_ptr(), ps.data_ptr(), w1a.data_ptr(),
                                                    b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(), w3p.data_ptr(),
                                                    b3.data_ptr(), e.data_ptr(), lib.stream_ptr())
@@ -329,6 +329,6 @@ def fc(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act: int)
     m, k = x.shape
     n = w.shape[0]
     y = torch.empty(m, n, dtype=torch.float32, device=x.device)
-    _call('dclr_fc', 'fc', m, n, k, x.data_ptr(), w.data_ptr(), lib.ptr(bias), act, y.data_ptr(),
+    _call('dclr_fc', 'fc[%d]' % m, m, n, k, x.data_ptr(), w.data_ptr(), lib.ptr(bias), act, y.data_ptr(),
                                  lib.stream_ptr())
     return y

@@ -34,6 +34,7 @@ class PipelinedForward:
         if group < 1 or (group > 1 and ahead == 'sample'):
             raise ValueError("group > 1 needs ahead='features' or 'knn'")
         self._model = model.eval()
+        model.prepare()                             # packed weights built here, on the caller's stream
         self.depth = depth
         self.group = group
         self._ahead = ahead

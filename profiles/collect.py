@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Collect the rocprofv3 evidence bench.py's roofline block refers to (run on the GPU box, from the repo root):
+
+    python3 profiles/collect.py --tag r02 [--configs c2,c4,c5] [--skip-pmc]
+
+Per config: (1) `rocprofv3 --kernel-trace --stats` over `python3 bench.py --config X ...` -> the kernel-stats CSV;
+(2) two SEPARATE `--pmc` passes (FETCH_SIZE, then WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md
+'rocprofv3 PMC slots'; never combined with a trace domain other than --kernel-trace) -> HBM bytes per launch.
+A calibration pass (a float4 copy of known size through torch) measures how FETCH_SIZE reads on this box for
+wide streaming loads (the guide: exactly 1/2 of the bytes on gfx950); `bytes_per_launch` = FETCH_SIZE x that
+factor + WRITE_SIZE, both raw figures are kept beside it. Everything is written under gpurun_out/<tag>/ (the
+only directory gpurun copies back); the summaries to commit are then copied into profiles/ by hand or with
+--install when run in the build container on the merged gpurun_out/.
+
+The JSON is stamped with the git commit (if known) and a hash of the kernel sources; bench.py attaches the figures
+to its `roofline.traffic` only when that hash matches the kernels it is running.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+KERNEL_TO_SPAN = [('fps_', 'fps_clouds'), ('sa_msg_kernel', 'sa_msg_fused'), ('knn_rows_kernel', 'knn_rows'),
+                  ('flow16_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding'),
+                  ('head16', 'head_conv_fused'), ('head_fused_kernel', 'head_conv_fused'),
+                  ('linear_kernel', 'linear_pair'), ('fc_kernel', 'fc')]
+BENCH_ARGS = {'c2': ['--steps', '8', '--warmup', '2'], 'c4': ['--steps', '4', '--warmup', '1'],
+              'c5': ['--steps', '6', '--warmup', '2']}
+CALIB = os.path.join(ROOT, 'profiles', 'calib_copy.py')
+
+
+def span_of(kernel_name: str, calib: bool = False):
+    if calib:
+        return 'calibration' if 'vectorized_elementwise_kernel' in kernel_name else None
+    for key, span in KERNEL_TO_SPAN:
+        if key in kernel_name:
+            return span
+    return None
+
+
+def run(cmd, log):
+    with open(log, 'w') as fh:
+        print('+', ' '.join(cmd), flush=True)
+        rc = subprocess.run(cmd, stdout=fh, stderr=subprocess.STDOUT, cwd=ROOT).returncode
+    if rc != 0:
+        raise SystemExit('{} failed with {} (see {})'.format(cmd[0], rc, log))
+
+
+def counter_rows(directory: str):
+    """(kernel name, counter name, value) from every *counter_collection.csv below `directory`."""
+    for path in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        with open(path, newline='') as fh:
+            for row in csv.DictReader(fh):
+                yield row['Kernel_Name'], row['Counter_Name'], float(row['Counter_Value'])
+
+
+def per_span_average(directory: str, counter: str, calib: bool = False):
+    acc = {}
+    for kname, cname, value in counter_rows(directory):
+        span = span_of(kname, calib)
+        if cname != counter or span is None:
+            continue
+        tot, cnt = acc.get(span, (0.0, 0))
+        acc[span] = (tot + value, cnt + 1)
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def git_commit():
+    try:
+        return subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True,
+                              check=True).stdout.strip()
+    except (OSError, subprocess.CalledProcessError):
+        return os.environ.get('DCLR_COMMIT', 'unknown (no .git on the GPU box)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--tag', required=True)
+    ap.add_argument('--configs', default='c2,c4,c5')
+    ap.add_argument('--skip-pmc', action='store_true')
+    ap.add_argument('--skip-stats', action='store_true')
+    ap.add_argument('--install', action='store_true', help='copy the summaries from gpurun_out/<tag>/ into profiles/')
+    args = ap.parse_args()
+    out = os.path.join(ROOT, 'gpurun_out', args.tag)
+    if args.install:
+        for path in glob.glob(os.path.join(out, '*')):
+            if os.path.isfile(path):
+                shutil.copy(path, os.path.join(ROOT, 'profiles', os.path.basename(path)))
+        traffic = os.path.join(out, '{}_pmc_traffic.json'.format(args.tag))
+        if os.path.exists(traffic):
+            shutil.copy(traffic, os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))
+        return
+    os.makedirs(out, exist_ok=True)
+    from bench import kernel_source_hash
+    doc = {'_how': __doc__.split('\n\n')[1].replace('\n', ' '), 'commit': git_commit(),
+           'kernel_source_hash': kernel_source_hash(), 'configs': {}}
+    py = sys.executable
+    fetch_factor = None
+    if not args.skip_pmc:
+        calib = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(out, 'raw_calib_' + counter)
+            run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--', py, CALIB],
+                os.path.join(out, 'calib_{}.log'.format(counter)))
+            calib[counter] = per_span_average(d, counter, calib=True).get('calibration', (0.0, 0))
+        known = 256 * 1024 * 1024                          # bytes read and bytes written by each calibration copy
+        fetch_factor = known / (calib['FETCH_SIZE'][0] * 1024) if calib['FETCH_SIZE'][0] else None
+        doc['calibration'] = {'known_bytes_read': known, 'known_bytes_written': known,
+                              'FETCH_SIZE_KB': calib['FETCH_SIZE'][0], 'WRITE_SIZE_KB': calib['WRITE_SIZE'][0],
+                              'launches': calib['FETCH_SIZE'][1],
+                              'fetch_factor': fetch_factor,
+                              'write_factor': known / (calib['WRITE_SIZE'][0] * 1024) if calib['WRITE_SIZE'][0] else None,
+                              'note': 'float4 streaming copy of 256 MiB (> Infinity Cache); MI355X_MICROARCH.md expects '
+                                      'fetch_factor 2.0 and write_factor 1.0 for 16 B/lane streams'}
+        print('calibration:', json.dumps(doc['calibration']), flush=True)
+    for cfg in args.configs.split(','):
+        bench = [py, 'bench.py', '--config', cfg, '--no-cpu-baseline'] + BENCH_ARGS[cfg]
+        if not args.skip_stats:
+            d = os.path.join(out, 'raw_stats_' + cfg)
+            run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--'] + bench + ['--no-launch-timer'],
+                os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, cfg)))
+            for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+                shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, cfg)))
+        if args.skip_pmc:
+            continue
+        spans = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(out, 'raw_pmc_{}_{}'.format(cfg, counter))
+            run(['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '--'] + bench + ['--no-launch-timer'],
+                os.path.join(out, 'pmc_{}_{}.log'.format(cfg, counter)))
+            for span, (avg, cnt) in per_span_average(d, counter).items():
+                spans.setdefault(span, {})[counter + '_KB'] = avg
+                spans[span]['launches_' + counter] = cnt
+        for span, rec in spans.items():
+            f, w = rec.get('FETCH_SIZE_KB', 0.0) * 1024, rec.get('WRITE_SIZE_KB', 0.0) * 1024
+            rec['bytes_per_launch_raw'] = f + w
+            rec['bytes_per_launch'] = f * (fetch_factor or 2.0) + w
+        doc['configs'][cfg] = spans
+        print(cfg, json.dumps(spans), flush=True)
+    if not args.skip_pmc:
+        path = os.path.join(out, '{}_pmc_traffic.json'.format(args.tag))
+        with open(path, 'w') as fh:
+            json.dump(doc, fh, indent=1)
+        print('wrote', path)
+    for d in glob.glob(os.path.join(out, 'raw_*')):        # keep gpurun_out small: the summaries are what travels
+        shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()

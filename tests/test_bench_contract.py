@@ -1,8 +1,13 @@
-"""bench.py without a GPU: the algorithmic work it prices kernels with, and the fields of its JSON contract."""
+"""bench.py without a GPU: the algorithmic work it prices kernels with, the launcher it becomes for --gpus N, and
+the fields of its JSON contract."""
 import importlib.util
+import json
 import os
+import subprocess
+import sys
 
 import pytest
+import torch
 
 from deepclr_amd import synthetic
 
@@ -19,28 +24,148 @@ def bench():
 
 def test_algorithmic_work_matches_the_design_figures(bench):
     cfg = synthetic.model_cfg('kitti')
-    pairs, n = 8, 16384
-    bound, flops = bench.algorithmic_work('flow_embedding', cfg, pairs, n, 2 * pairs)
+    pairs = 8
+    bound, flops, _ = bench.algorithmic_work('flow_embedding[8x1024x20]', cfg)
     rows = pairs * 1024 * 20
     assert bound == 'mfma' and flops == 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5
     assert abs(flops / pairs - 2.01e9) < 0.05e9                       # 2.01 GFLOP per pair (+ layer-1 rest)
-    bound, flops = bench.algorithmic_work('head_conv_fused', cfg, pairs, n, 2 * pairs)
+    bound, flops, _ = bench.algorithmic_work('head_conv_fused[8x1024]', cfg)
     assert bound == 'mfma' and abs(flops / pairs - 2.15e9) < 0.02e9    # 1024 x 1,049,344 MAC (+ 5 padded input columns)
-    bound, flops = bench.algorithmic_work('linear_pair[2x8192x128x64]', cfg, pairs, n, 2 * pairs)
+    bound, flops, _ = bench.algorithmic_work('linear_pair[2x8192x128x64]', cfg)
     assert bound == 'mfma' and flops == 4.0 * 8192 * 128 * 64
-    bound, nbytes = bench.algorithmic_work('fps_clouds', cfg, pairs, n, 2 * pairs)
-    assert bound == 'hbm' and nbytes == 16 * (16384 * 4 * 4 + 1024 * 4)
-    bound, nbytes = bench.algorithmic_work('sa_msg_fused', cfg, pairs, n, 2 * pairs)
-    assert bound == 'hbm' and nbytes == 16 * (16384 * 16 + 1024 * 4 + 1024 * 68 * 4)
+    bound, nbytes, _ = bench.algorithmic_work('knn_rows[8x1024x20]', cfg)
+    assert bound == 'hbm' and nbytes == 8 * 1024 * (2 * 68 * 4 + 20 * 4)
+    bound, nbytes, extra = bench.algorithmic_work('fc[8]', cfg)
+    layers = [(1024, 512), (512, 256), (256, 8)]
+    assert bound == 'hbm' and nbytes == sum((a * b + 8 * a + 8 * b) * 4.0 for a, b in layers) / 3 and nbytes > 0
+
+
+def test_grouped_launches_are_priced_per_launch(bench):
+    """One sampling / set-abstraction launch of the pipelined run covers group x 2B clouds (c2: 4 x 16 = 64): the
+    span name carries the launch's own size, so the figures scale with it (they were 4x low)."""
+    cfg = synthetic.model_cfg('kitti')
+    b16 = bench.algorithmic_work('sa_msg_fused[16x16384]', cfg)
+    b64 = bench.algorithmic_work('sa_msg_fused[64x16384]', cfg)
+    assert b16[0] == 'hbm' and b16[1] == 16 * (16384 * 16 + 1024 * 4 + 1024 * 68 * 4) and b64[1] == 4 * b16[1]
+    assert b64[2]['clouds_per_launch'] == 64
+    bound, flop, extra = bench.algorithmic_work('fps_clouds[64x16384]', cfg)
+    assert bound == 'valu-latency'                                             # a latency chain, not an HBM stream
+    assert extra['dist_evals'] == 64 * 1023 * 16384 and flop == extra['dist_evals'] * bench.FPS_FLOP_PER_EVAL
+    assert extra['samples_per_cloud'] == 1023 and extra['clouds_per_launch'] == 64
+    # ModelNet architecture: npoint 512, k 30
+    mcfg = synthetic.model_cfg('modelnet')
+    _, flop, extra = bench.algorithmic_work('fps_clouds[512x2048]', mcfg)
+    assert extra['dist_evals'] == 512 * 511 * 2048
+    _, flops, _ = bench.algorithmic_work('flow_embedding[256x512x30]', mcfg)
+    # SURVEY 8(d) counts 1.013 GMAC per ModelNet pair with layer 1 applied per neighbour row (131 -> 128); the fused
+    # design evaluates the two feature blocks of layer 1 once per POINT (linear_pair), leaving 5 columns per row
+    assert flops / 256 == 2.0 * 512 * 30 * (128 * 128 + 128 * 256 + 128 * 5)
 
 
 def test_peaks_and_workload_constants(bench):
     assert bench.PAIRS_PER_GPU == 8 and bench.POINTS == 16384                  # BASELINE.json configs[1]
+    assert bench.CONFIGS['c4']['pairs'] == 256 and bench.CONFIGS['c4']['points'] == 2048      # configs[3]
+    assert bench.CONFIGS['c5']['pairs'] == 4 and bench.CONFIGS['c5']['points'] == 65536       # configs[4]
     assert bench.FP32_MATRIX_PEAK_TFLOPS == 157.3 and bench.HBM_PEAK_GBS == 8000.0
     assert abs(bench.F16_MATRIX_PEAK_TFLOPS / bench.SPLIT_PRODUCTS - 838.9) < 0.1
     assert os.environ.get('GPU_MAX_HW_QUEUES') is not None                     # set on import, before HIP initialises
+    args = bench.parse_args([])
+    assert (args.config, args.gpus, args.group, args.depth) == ('c2', 1, 4, 3) and args.steps >= 100
+    args = bench.parse_args(['--config', 'c4', '--steps', '7'])
+    assert (args.group, args.depth, args.steps) == (1, 2, 7)
 
 
 def test_launch_timer_sampling_is_coprime_with_group_sizes(bench):
     for group in (2, 3, 4):
         assert bench.LaunchTimer.SAMPLE_EVERY % group != 0
+
+
+def test_rank_environments_of_the_self_launcher(bench):
+    envs = bench.rank_environments(4, 23456, base_env={'PATH': '/bin', 'WORLD_SIZE': 'stale'})
+    assert [e['RANK'] for e in envs] == ['0', '1', '2', '3'] and [e['LOCAL_RANK'] for e in envs] == ['0', '1', '2', '3']
+    assert all(e['WORLD_SIZE'] == '4' and e['MASTER_ADDR'] == '127.0.0.1' and e['MASTER_PORT'] == '23456' for e in envs)
+    assert all(e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and e['PATH'] == '/bin' for e in envs)
+    assert 0 < bench.free_port() < 65536
+
+
+def test_self_launcher_spawns_before_any_gpu_call_and_relays_rank0(bench, tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` without WORLD_SIZE: two children with rank environments, rank 0's JSON relayed,
+    a failing rank makes the launcher fail. The children here are a stub script (no GPU in this container)."""
+    stub = tmp_path / 'stub_bench.py'
+    stub.write_text(
+        "import json, os, sys\n"
+        "r = int(os.environ['RANK'])\n"
+        "assert os.environ['WORLD_SIZE'] == '2' and os.environ['LOCAL_RANK'] == str(r) and os.environ['DCLR_BENCH_CHILD'] == '1'\n"
+        "if '--fail' in sys.argv and r == 1: sys.exit(3)\n"
+        "if r == 0: print(json.dumps({'metric': 'stub', 'n_gpus': 2, 'argv': sys.argv[1:]}))\n")
+    monkeypatch.setattr(bench.os.path, 'abspath', lambda p: str(stub) if p == bench.__file__ else os.path.normpath(os.path.join(os.getcwd(), p)))
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.spawn_ranks(2, ['--gpus', '2', '--steps', '3'])
+    assert rc == 0
+    line = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['argv'] == ['--gpus', '2', '--steps', '3']
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert bench.spawn_ranks(2, ['--gpus', '2', '--fail']) == 3
+
+
+def test_main_becomes_the_launcher_only_without_world_size(bench, monkeypatch):
+    calls = []
+    monkeypatch.setattr(bench, 'spawn_ranks', lambda n, argv: calls.append((n, list(argv))) or 0)
+    monkeypatch.setattr(bench, 'run', lambda args: calls.append(('run', args.gpus)))
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main(['--gpus', '8', '--steps', '5', '--warmup', '1'])
+    assert e.value.code == 0 and calls == [(8, ['--gpus', '8', '--steps', '5', '--warmup', '1'])]
+    monkeypatch.setenv('WORLD_SIZE', '8')                  # under torch.distributed.run: a rank, not a launcher
+    bench.main(['--gpus', '8'])
+    assert calls[-1] == ('run', 8)
+    monkeypatch.delenv('WORLD_SIZE')
+    bench.main(['--gpus', '1'])
+    assert calls[-1] == ('run', 1)
+
+
+def test_output_gather_bookkeeping_world_size_2(bench, tmp_path):
+    """The send / gather_every bookkeeping of bench.py's N > 1 path on gloo, two ranks (CPU)."""
+    script = tmp_path / 'gather_worker.py'
+    script.write_text(
+        "import importlib.util, os, sys, torch, torch.distributed as dist\n"
+        "spec = importlib.util.spec_from_file_location('b', sys.argv[1]); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "dist.init_process_group('gloo')\n"
+        "rank, world = dist.get_rank(), dist.get_world_size()\n"
+        "g = b.OutputGather(dist, world, 3, 4, 8, 'cpu')\n"
+        "for step in range(7):\n"
+        "    y = torch.full((4, 8), float(100 * rank + step))\n"
+        "    if step % 2 == 0:\n"
+        "        g.slot().copy_(y); g.put(None)\n"
+        "    else:\n"
+        "        g.put(y)\n"
+        "    if step == 5:\n"
+        "        got = g.gathered.view(world, 3, 4, 8)\n"
+        "        assert g.collectives == 2 and g.filled == 0\n"
+        "        for r in range(world):\n"
+        "            for s in range(3):\n"
+        "                assert bool((got[r, s] == 100 * r + 3 + s).all()), (r, s, got[r, s, 0, 0])\n"
+        "g.flush(); assert g.collectives == 3 and g.filled == 0\n"
+        "assert float(g.gathered.view(world, 3, 4, 8)[1, 0, 0, 0]) == 106.0\n"
+        "seen = [None] * world; dist.all_gather_object(seen, rank); assert seen == [0, 1]\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    envs = bench.rank_environments(2, bench.free_port())
+    procs = [subprocess.Popen([sys.executable, str(script), os.path.join(ROOT, 'bench.py')], env=e) for e in envs]
+    assert [p.wait(timeout=300) for p in procs] == [0, 0]
+
+
+def test_traffic_figures_attach_only_to_the_kernels_they_were_measured_on(bench, tmp_path, monkeypatch):
+    path = tmp_path / 'pmc_traffic.json'
+    monkeypatch.setattr(bench, 'TRAFFIC_FILE', str(path))
+    assert bench.load_traffic()[0] == {}
+    path.write_text(json.dumps({'kernel_source_hash': 'deadbeef', 'commit': 'abc', 'configs': {'c2': {'x': {}}}}))
+    got, why = bench.load_traffic()
+    assert got == {} and 'other kernel sources' in why
+    path.write_text(json.dumps({'kernel_source_hash': bench.kernel_source_hash(), 'commit': 'abc',
+                                'configs': {'c2': {'head_conv_fused': {'bytes_per_launch': 123}}}}))
+    got, why = bench.load_traffic()
+    assert got['c2']['head_conv_fused']['bytes_per_launch'] == 123 and 'abc' in why

@@ -338,6 +338,70 @@ def test_other_baseline_configs_against_oracle(kind, n, pairs):
     assert pose_delta(_mats(y), mats_o) < 1e-4
 
 
+@pytest.mark.parametrize('kind,n,pairs,npoint', [('modelnet', 2048, 256, 512), ('kitti', 65536, 4, 1024)])
+def test_full_size_c4_c5_batches_properties_and_oracle_pairs(kind, n, pairs, npoint):
+    """BASELINE.json configs[3] (C4: 256 ModelNet pairs of 2 x 2048 points = 512 clouds per batch, k = 30) and
+    configs[4] (C5: 4 pairs of 2 x 65536 points, paged sampler + exhaustive set-abstraction sweep) AT FULL SIZE:
+    whole-batch properties (no point sampled twice, greedy invariant, pairs independent of the batch they travel
+    in -- bit-identical against sub-batches) and oracle parity on two pairs."""
+    cfg = synthetic.model_cfg(kind)
+    sd = synthetic.random_state_dict(cfg, seed=5)
+    model, orc = _models(cfg, sd)
+    x_np = synthetic.make_batch(kind, pairs, n, first_pair=300)
+    x = torch.from_numpy(x_np).to(DEV)
+    assert tuple(x.shape) == (2 * pairs, n, cfg['input_dim'])
+    fps = ops.fps_clouds(x, npoint).long()
+    assert (fps[:, 0] == 0).all() and int(fps.min()) >= 0 and int(fps.max()) < n
+    srt = fps.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                            # no point sampled twice
+    sel = list(range(0, 2 * pairs, max(1, 2 * pairs // 16)))                  # greedy invariant on a spread of clouds
+    pts = torch.gather(x[sel, :, :3], 1, fps[sel][:, :, None].expand(-1, -1, 3)).double()
+    d = torch.cdist(pts, pts)
+    mask = torch.tril(torch.ones(npoint, npoint, dtype=torch.bool, device=DEV), diagonal=-1)
+    reach = torch.where(mask, d, torch.full_like(d, float('inf'))).min(dim=2).values[:, 1:]
+    assert (reach[:, 1:] <= reach[:, :-1] + 1e-9).all()
+    half = pairs // 2
+    sub = list(range(half)) + list(range(pairs, pairs + half))
+    with torch.no_grad():
+        y, _, _ = model(x.clone())
+        y_half, _, _ = model(x[sub].clone())
+        y_two, _, _ = model(x[[0, 1, pairs, pairs + 1]].clone())
+    assert tuple(y.shape) == (pairs, 8) and bool(torch.isfinite(y).all())
+    assert torch.equal(y[:half], y_half) and torch.equal(y[:2], y_two)        # pairs are independent
+    y_o = orc(torch.from_numpy(x_np[[0, 1, pairs, pairs + 1]]))
+    _close(y[:2], y_o)
+    assert pose_delta(_mats(y[:2]), np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])) < 1e-4
+    # through the pipelined runner (what bench.py --config c4 / c5 times): identical outputs
+    from deepclr_amd.pipeline import PipelinedForward
+    runner = PipelinedForward(model, depth=2, ahead='knn', group=1 if kind == 'modelnet' else 2)
+    got = list(runner.run([x, x, x]))
+    assert all(torch.equal(g, y) for g in got)
+
+
+def test_pipelined_runner_cold_start_on_side_streams():
+    """A freshly built model whose very first use is the pipelined runner: the weight-packing kernels are enqueued
+    by whichever stream asks first, every other stream must be ordered behind them (PackedCache events)."""
+    from deepclr_amd.pipeline import PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=12)
+    batches = [torch.from_numpy(synthetic.make_batch('kitti', 2, 4096, first_pair=20 + 3 * i)).to(DEV) for i in range(6)]
+    for trial in range(3):
+        fresh = build_model(model_config_from_dict(cfg))
+        fresh.load_state_dict(sd, strict=True)
+        fresh = fresh.to(DEV).eval()
+        got = list(PipelinedForward(fresh, depth=3, ahead='knn', group=2).run(batches))
+        if trial == 0:
+            with torch.no_grad():
+                want = [fresh(b)[0] for b in batches]
+        assert all(torch.equal(a, b) for a, b in zip(got, want))
+    # parameters replaced AFTER the runner was built: the rebuild happens on a side stream
+    fresh = build_model(model_config_from_dict(cfg)).to(DEV).eval()
+    runner = PipelinedForward(fresh, depth=3, ahead='knn', group=2)
+    fresh.load_state_dict(sd, strict=True)
+    got = list(runner.run(batches))
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
 def test_pipelined_runner_matches_plain_forward():
     from deepclr_amd.pipeline import PipelinedForward
     cfg = synthetic.model_cfg('kitti')
