@@ -47,11 +47,11 @@ from deepclr_amd.pipeline import PipelinedForward, PipelinedSequence           #
 # pipelined runner (the sampler is one workgroup per cloud: c2 needs grouped launches to have enough clouds in
 # flight, c4 already brings 512 clouds per batch).
 CONFIGS = {
-    'c2': {'kind': 'kitti', 'pairs': 8, 'points': 16384, 'depth': 3, 'group': 4, 'steps': 200, 'warmup': 20,
+    'c2': {'kind': 'kitti', 'pairs': 8, 'points': 16384, 'depth': 3, 'group': 4, 'dense_group': 1, 'steps': 200, 'warmup': 20,
            'baseline': 'BASELINE.json configs[1]'},
-    'c4': {'kind': 'modelnet', 'pairs': 256, 'points': 2048, 'depth': 2, 'group': 1, 'steps': 40, 'warmup': 5,
+    'c4': {'kind': 'modelnet', 'pairs': 256, 'points': 2048, 'depth': 2, 'group': 1, 'dense_group': 0, 'steps': 40, 'warmup': 5,
            'baseline': 'BASELINE.json configs[3]'},
-    'c5': {'kind': 'kitti', 'pairs': 4, 'points': 65536, 'depth': 3, 'group': 2, 'steps': 100, 'warmup': 10,
+    'c5': {'kind': 'kitti', 'pairs': 4, 'points': 65536, 'depth': 3, 'group': 2, 'dense_group': 1, 'steps': 100, 'warmup': 10,
            'baseline': 'BASELINE.json configs[4]'},
 }
 PAIRS_PER_GPU = CONFIGS['c2']['pairs']
@@ -132,25 +132,32 @@ def spawn_ranks(n: int, argv) -> int:
 # per-kernel HIP events
 # ----------------------------------------------------------------------------------------------------------
 class LaunchTimer:
-    """HIP events around every library launch, on the stream the kernel is enqueued on."""
+    """HIP events around library launches, on the stream the kernel is enqueued on. Every SAMPLE_EVERY-th launch
+    of each kind is bracketed (the events themselves cost ~10 % when put around everything); counted per kind,
+    not per step, so that launches covering several batches (one sampling / dense launch per `group` steps) are
+    sampled at the same rate whatever the warm-up count."""
 
-    SAMPLE_EVERY = 5       # bracket the launches of every 5th step only (the events themselves cost ~10 %); coprime
-                           # with the 2-4 batches per sampling launch, or those launches would never be sampled
+    SAMPLE_EVERY = 3
 
     def __init__(self, sample_every=None):
         self.spans = []
         self.raw = []
+        self.calls = {}
         self._hip = None
         self.main_stream = torch.cuda.current_stream().cuda_stream
-        self.step = 0
         if sample_every is not None:
             self.SAMPLE_EVERY = sample_every
 
     def next_step(self):
-        self.step += 1
+        pass
+
+    def _sampled(self, kind: str) -> bool:
+        n = self.calls.get(kind, 0)
+        self.calls[kind] = n + 1
+        return n % self.SAMPLE_EVERY == 0
 
     def begin(self, name):
-        if self.step % self.SAMPLE_EVERY != 0:
+        if not self._sampled(name):
             return None
         start = torch.cuda.Event(enable_timing=True)
         start.record()
@@ -163,10 +170,18 @@ class LaunchTimer:
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
 
-    def merge_events(self, pairs, npoint, k, n_fc=3):
+    def merge_events(self, pairs, npoint, k, n_fc=3, stages=3):
         """Raw HIP events for the stages of one dclr_merge_forward call (the dense stages are one foreign call;
-        the library records these between its launches, on the launch stream)."""
-        if self.step % self.SAMPLE_EVERY != 0:
+        the library records these between its launches, on the launch stream). stages: the call's stage mask
+        (1 = layer-1 halves + kNN, 2 = flow embedding + head + FC tail)."""
+        rows = pairs * npoint
+        names = ['linear_pair[2x%dx128x64]' % rows, None, 'knn_rows[%dx%dx%d]' % (pairs, npoint, k),
+                 'flow_embedding[%dx%dx%d]' % (pairs, npoint, k), 'head_conv_fused[%dx%d]' % (pairs, npoint)]
+        names += ['fc[%d]' % pairs] * n_fc
+        live = [n for i, n in enumerate(names) if n is not None and ((stages & 1 and i < 3) or (stages & 2 and i >= 3))]
+        for n in set(live):
+            self.calls[n] = self.calls.get(n, 0) + live.count(n)
+        if not self._sampled('merge_forward/%d' % stages):
             return None
         import ctypes
         from deepclr_amd import lib
@@ -178,10 +193,6 @@ class LaunchTimer:
             if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
                 return None
             arr[i] = ev.value
-        rows = pairs * npoint
-        names = ['linear_pair[2x%dx128x64]' % rows, None, 'knn_rows[%dx%dx%d]' % (pairs, npoint, k),
-                 'flow_embedding[%dx%dx%d]' % (pairs, npoint, k), 'head_conv_fused[%dx%d]' % (pairs, npoint)]
-        names += ['fc[%d]' % pairs] * n_fc
         on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
         self.raw.append((arr, names, on_main))
         return arr
@@ -202,7 +213,8 @@ class LaunchTimer:
                     continue
                 tot, cnt, _ = acc.get(name, (0.0, 0, on_main))
                 acc[name] = (tot + ms.value, cnt + 1, on_main)
-        return {k: {'total_ms': v[0], 'launches': v[1], 'avg_us': 1e3 * v[0] / v[1], 'main_stream': v[2]}
+        return {k: {'total_ms': v[0], 'sampled': v[1], 'launches': self.calls.get(k, v[1]), 'avg_us': 1e3 * v[0] / v[1],
+                    'main_stream': v[2]}
                 for k, v in acc.items()}
 
 
@@ -309,13 +321,16 @@ def parse_args(argv=None):
                     help='odometry mode (not the BASELINE metric): each step is a chunk of 16 consecutive frames of '
                          'one sequence = 16 pairs, every frame sampled and abstracted once')
     ap.add_argument('--group', type=int, default=None, help='batches sampled by one launch on a side stream')
+    ap.add_argument('--dense-group', type=int, default=None, choices=[0, 1],
+                    help='1: the dense stages (flow embedding, head, FC tail) of the batches sampled together also run '
+                         'as one launch sequence over group x B pairs')
     ap.add_argument('--gather-every', type=int, default=4, help='steps whose outputs share one all-gather (N > 1)')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
     args = ap.parse_args(argv)
     wl = CONFIGS[args.config]
-    for key in ('steps', 'warmup', 'depth', 'group'):
+    for key in ('steps', 'warmup', 'depth', 'group', 'dense_group'):
         if getattr(args, key) is None:
             setattr(args, key, wl[key])
     return args
@@ -385,8 +400,9 @@ def run(args):
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:
+        dense_group = bool(args.dense_group) and args.ahead == 'knn' and args.group > 1
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
-                                                               group=args.group)
+                                                               group=args.group, dense_group=dense_group)
     if runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
@@ -399,15 +415,30 @@ def run(args):
         dist.all_gather_into_tensor(seen, mine)
         ranks_seen = [int(v) for v in seen.cpu()]
 
+    in_place_left = [0]
+
     def step():
-        in_place = gather is not None and runner is not None and not args.sequence
+        # the outputs go straight into the all-gather's send buffer where the runner allows it: one slot per step,
+        # or the slots of a whole dense group at its first step
+        out = None
+        if gather is not None and runner is not None and not args.sequence:
+            span = runner.group_start(x)
+            if span == 0 and in_place_left[0] == 0 and not runner._dense_group:
+                out, in_place_left[0] = gather.slot(), 1
+            elif span > 0 and gather.filled + span <= gather.every:
+                out = gather.send[gather.filled:gather.filled + span].view(span * pairs_per_step, -1)
+                in_place_left[0] = span
         if runner is not None:
-            y = runner.step(x, upcoming=[x], out=gather.slot() if in_place else None)
+            y = runner.step(x, upcoming=[x], out=out)
         else:
             with torch.no_grad():
                 y, _, _ = model(x)
         if gather is not None:
-            gather.put(None if in_place else y)
+            if in_place_left[0] > 0:
+                in_place_left[0] -= 1
+                gather.put(None)
+            else:
+                gather.put(y)
         return y
 
     def fence():
@@ -436,17 +467,23 @@ def run(args):
         solo = LaunchTimer(sample_every=1)
         ops.TIMER = solo
         with torch.no_grad():
-            xs = torch.cat([x] * args.group) if (args.group > 1 and not args.sequence and runner is not None) else x
+            g = args.group if (args.group > 1 and not args.sequence and runner is not None) else 1
+            dense_g = g if getattr(runner, '_dense_group', False) else 1
+            half = x.shape[0] // 2
+            xs = torch.cat([x[:half]] * g + [x[half:]] * g) if dense_g > 1 else torch.cat([x] * g)
             for _ in range(6):
                 if args.sequence:
                     f_rows = model.cloud_feature_rows(x)
                     rows, pairs, _ = model.sequence_rows(f_rows, x.shape[0], f_rows[-model.npoint:])
                     model.merge_rows(rows, pairs)
                 else:
-                    # the sampling stages at the launch size of the timed region (group x 2B clouds), the dense
-                    # stages per batch
+                    # the same launch sizes as the timed region: sampling stages over group x 2B clouds, the dense
+                    # stages over the batches of one dense launch
                     f_all = model.cloud_feature_rows(xs)
-                    model.merge_rows(f_all[:x.shape[0] * model.npoint], x.shape[0] // 2)
+                    if dense_g > 1:
+                        model.merge_rows(f_all, half * g)
+                    else:
+                        model.merge_rows(f_all[:x.shape[0] * model.npoint], half)
         torch.cuda.synchronize()
         ops.TIMER = None
         alone = solo.summary()
@@ -462,7 +499,6 @@ def run(args):
         traffic = traffic_all.get(args.config, {})
         if timer is not None:
             kernels = timer.summary()
-            sampled_steps = len(range(0, args.steps, LaunchTimer.SAMPLE_EVERY))
 
             def roof(name):
                 bound, units, extra = algorithmic_work(name, cfg)
@@ -493,7 +529,9 @@ def run(args):
                        'traffic': None if tr is None else tr.get('bytes_per_launch'),
                        'avg_us': kernels[name]['avg_us'], 'alone_us': solo_us,
                        'frac_alone': None if solo_us is None else achieved / peak * kernels[name]['avg_us'] / solo_us,
-                       'share_of_step': (kernels[name]['total_ms'] / max(1, sampled_steps)) / (1e3 * elapsed / args.steps),
+                       'launches': kernels[name]['launches'], 'sampled_launches': kernels[name]['sampled'],
+                       # this kernel's launches in the timed region x its average duration / the region
+                       'share_of_step': kernels[name]['avg_us'] * 1e-6 * kernels[name]['launches'] / elapsed,
                        'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
                 out.update(extra)
                 return out
@@ -501,8 +539,9 @@ def run(args):
             # dominant kernel = largest total time on the stream that bounds the step (the main one);
             # the side-stream sampler is latency-bound by construction and listed in `rooflines`
             main = [k for k in kernels if kernels[k]['main_stream']] or list(kernels)
-            roofline = roof(max(main, key=lambda k: kernels[k]['total_ms']))
-            rooflines = [roof(k) for k in sorted(kernels, key=lambda k: -kernels[k]['total_ms'])[:8]]
+            weight = lambda k: kernels[k]['avg_us'] * kernels[k]['launches']            # noqa: E731
+            roofline = roof(max(main, key=weight))
+            rooflines = [roof(k) for k in sorted(kernels, key=lambda k: -weight(k))[:8]]
         result = {
             'metric': 'scan-pairs/sec (2x{} pts)'.format(points), 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -519,7 +558,9 @@ def run(args):
                        'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
                        'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
-                                                                args.group, 'ahead': args.ahead}},
+                                                                args.group, 'ahead': args.ahead,
+                                                                'batches_per_dense_launch':
+                                                                args.group if getattr(runner, '_dense_group', False) else 1}},
             'ranks_seen': ranks_seen,
             'collectives': None if gather is None else {'all_gathers': gather.collectives, 'steps_per_all_gather': gather.every,
                                                          'bytes_per_rank': int(gather.send.numel() * 4)},

@@ -497,7 +497,7 @@ class DeepCLR(BaseModel):
         plan = self._merge_plan(f_rows, pairs)
         if plan is None:
             return None
-        events = ops.TIMER.merge_events(pairs, self.npoint, plan.args.k, plan.args.n_fc) if ops.TIMER is not None else None
+        events = ops.TIMER.merge_events(pairs, self.npoint, plan.args.k, plan.args.n_fc, 1) if ops.TIMER is not None else None
         return plan.prep(f_rows, events)
 
     def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None, prep=None,
@@ -508,7 +508,8 @@ class DeepCLR(BaseModel):
         plan = self._merge_plan(f_rows, pairs)
         if plan is not None:
             if events is None and ops.TIMER is not None:
-                events = ops.TIMER.merge_events(pairs, self.npoint, plan.args.k, plan.args.n_fc)   # per-stage HIP events
+                events = ops.TIMER.merge_events(pairs, self.npoint, plan.args.k, plan.args.n_fc,
+                                                3 if prep is None else 2)               # per-stage HIP events
             return plan.run(f_rows, events, prep, out)
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         y = self._merge_layers[1].forward_rows(e_rows, pairs)

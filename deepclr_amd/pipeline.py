@@ -16,7 +16,8 @@ from .models.deepclr import DeepCLR
 
 
 class PipelinedForward:
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
+                 dense_group: bool = False):
         """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
         abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
         the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
@@ -26,7 +27,13 @@ class PipelinedForward:
         runtime multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES; bench.py raises it to
         8 so that RCCL's own stream does not share a queue with a sampling launch) and more than 3 side streams
         measured slower either way -- grouping is how more clouds get in flight (their inputs are concatenated
-        on the side stream)."""
+        on the side stream).
+        dense_group (needs ahead='knn'): the dense stages of the `group` batches sampled together also run as ONE
+        launch sequence (flow embedding, head and fully connected tail over group x B pairs, enqueued when the
+        first batch of the group is stepped): a single batch of 8 KITTI pairs is 8192 head rows = 128 workgroups,
+        half the chip, and three ~13 us fully connected launches per batch were a fifth of the main stream."""
+        if dense_group and (ahead != 'knn' or group < 2):
+            raise ValueError("dense_group needs ahead='knn' and group > 1")
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if ahead not in ('sample', 'features', 'knn'):
@@ -38,6 +45,8 @@ class PipelinedForward:
         self.depth = depth
         self.group = group
         self._ahead = ahead
+        self._dense_group = dense_group
+        self._group_out = None                      # (batches of the running dense group, their outputs)
         self._waiting = []                          # batches collected for the next grouped launch
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
         self._next_stream = 0
@@ -66,6 +75,19 @@ class PipelinedForward:
             else:
                 if any(b.shape != xs[0].shape for b in xs):
                     raise RuntimeError("batches sampled in one launch must have the same shape")
+                if self._dense_group:
+                    # [templates of every batch | sources of every batch]: the reference's batch layout for
+                    # len(xs) * B pairs, so the dense stages can take all of them in one go
+                    half = xs[0].shape[0] // 2
+                    big = torch.cat([b[:half] for b in xs] + [b[half:] for b in xs])
+                    rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+                    prep = self._model.merge_prep(rows, half * len(xs))
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    for b in xs:
+                        b.record_stream(side)
+                    self._pending.append((xs, (rows, prep), done))
+                    return
                 big = torch.cat(xs)
                 rows = self._model.cloud_feature_rows(big, self._model.sample(big))
                 outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
@@ -78,7 +100,22 @@ class PipelinedForward:
             self._pending.append((b, out, done))
 
     def in_flight(self) -> int:
-        return len(self._pending) + len(self._waiting)
+        running = len(self._group_out[0]) if self._group_out is not None else 0     # dense stages enqueued, not yet stepped
+        return sum(len(p[0]) if isinstance(p[0], list) else 1 for p in self._pending) + len(self._waiting) + running
+
+    def group_start(self, x: torch.Tensor) -> int:
+        """Number of batches whose outputs the next step(x) will produce in one go (0: none, x continues a running
+        group or is a single batch): callers that want the outputs written into a buffer of their own hand step()
+        an `out` of that many batches."""
+        if not self._dense_group:
+            return 0
+        if self._group_out is not None and self._group_out[0] and self._group_out[0][0] is x:
+            return 0
+        if self._pending and isinstance(self._pending[0][0], list) and self._pending[0][0][0] is x:
+            return len(self._pending[0][0])
+        if not self._pending and self._waiting and self._waiting[0] is x:
+            return len(self._waiting)
+        return 0
 
     def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = (),
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -87,8 +124,36 @@ class PipelinedForward:
         stages are enqueued, so they run beside them."""
         main = torch.cuda.current_stream()
         ready = None
+        if self._group_out is not None and self._group_out[0] and self._group_out[0][0] is x:
+            # a batch of the dense group already enqueued: its outputs are a slice of that launch's result
+            batches, y_all = self._group_out
+            pos = y_all.shape[0] // (x.shape[0] // 2) - len(batches)
+            batches.pop(0)
+            for nxt in upcoming:
+                if self.in_flight() >= self.depth * self.group:
+                    break
+                self.prefetch(nxt, flush=False)
+            y = y_all[pos * (x.shape[0] // 2):(pos + 1) * (x.shape[0] // 2)]
+            return y if out is None else out.copy_(y)
         if not self._pending and self._waiting and self._waiting[0] is x:
             self._launch()                                   # end of a stream of batches: the group never filled
+        if self._pending and isinstance(self._pending[0][0], list) and self._pending[0][0][0] is x:
+            xs, (rows, prep), done = self._pending.popleft()
+            main.wait_event(done)
+            for t in self._tensors((rows, prep)):
+                t.record_stream(main)
+            for nxt in upcoming:
+                if self.in_flight() >= self.depth * self.group:
+                    break
+                self.prefetch(nxt, flush=False)
+            pairs = x.shape[0] // 2
+            want = len(xs) * pairs
+            whole = out is not None and out.shape[0] == want
+            with torch.no_grad():
+                y_all = self._model.merge_rows(rows, want, prep=prep, out=out if whole else None)
+            self._group_out = (list(xs[1:]), y_all)
+            y = y_all[:pairs]
+            return y if (out is None or whole) else out.copy_(y)
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
             main.wait_event(done)

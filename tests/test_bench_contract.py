@@ -75,9 +75,19 @@ def test_peaks_and_workload_constants(bench):
     assert (args.group, args.depth, args.steps) == (1, 2, 7)
 
 
-def test_launch_timer_sampling_is_coprime_with_group_sizes(bench):
-    for group in (2, 3, 4):
-        assert bench.LaunchTimer.SAMPLE_EVERY % group != 0
+def test_launch_timer_samples_per_kind_not_per_step(bench, monkeypatch):
+    """Launches that cover several batches (one per `group` steps) must be sampled whatever the warm-up count."""
+    class _Ev:
+        def __init__(self, enable_timing=True): pass
+        def record(self): pass
+    class _S:
+        cuda_stream = 7
+    monkeypatch.setattr(bench.torch.cuda, 'Event', _Ev)
+    monkeypatch.setattr(bench.torch.cuda, 'current_stream', lambda: _S())
+    t = bench.LaunchTimer()
+    hits = [t.begin('fps_clouds[64x16384]') is not None for _ in range(9)]
+    assert hits == [True, False, False] * 3 and t.calls['fps_clouds[64x16384]'] == 9
+    assert t.begin('sa_msg_fused[64x16384]') is not None                      # kinds are counted separately
 
 
 def test_rank_environments_of_the_self_launcher(bench):

@@ -409,11 +409,30 @@ def test_pipelined_runner_matches_plain_forward():
     batches = [torch.from_numpy(synthetic.make_batch('kitti', 2, 4096, first_pair=10 * i)).to(DEV) for i in range(5)]
     with torch.no_grad():
         want = [model(b)[0] for b in batches]
-    for ahead, group in (('sample', 1), ('features', 1), ('features', 2), ('features', 3), ('knn', 1), ('knn', 2)):
-        got = list(PipelinedForward(model, depth=2, ahead=ahead, group=group).run(batches))
+    for ahead, group, dense in (('sample', 1, False), ('features', 1, False), ('features', 2, False), ('features', 3, False),
+                                ('knn', 1, False), ('knn', 2, False), ('knn', 2, True), ('knn', 3, True), ('knn', 4, True)):
+        got = list(PipelinedForward(model, depth=2, ahead=ahead, group=group, dense_group=dense).run(batches))
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+    # dense groups writing straight into a caller's buffer: whole groups at their first step, singles otherwise
+    runner = PipelinedForward(model, depth=2, ahead='knn', group=2, dense_group=True)
+    slots = torch.zeros(len(batches), want[0].shape[0], want[0].shape[1], device=DEV)
+    i = 0
+    while i < len(batches):
+        span = runner.group_start(batches[i])
+        if span > 1:
+            y = runner.step(batches[i], batches[i + 1:], out=slots[i:i + span].view(-1, slots.shape[-1]))
+            assert y.data_ptr() == slots[i].data_ptr()
+            for j in range(1, span):
+                assert runner.group_start(batches[i + j]) == 0
+                y = runner.step(batches[i + j], batches[i + j + 1:])
+                assert y.data_ptr() == slots[i + j].data_ptr()
+            i += span
+        else:
+            runner.step(batches[i], batches[i + 1:], out=slots[i])
+            i += 1
+    assert torch.equal(slots, torch.stack(want))
     # results written straight into a caller's buffer (what bench.py hands to the all-gather)
     runner = PipelinedForward(model, depth=2, ahead='knn', group=2)
     slots = torch.zeros(len(batches), want[0].shape[0], want[0].shape[1], device=DEV)
