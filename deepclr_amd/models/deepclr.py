@@ -200,9 +200,32 @@ class OutputSimple(DeepCLRModule):
         self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
         self._cache = PackedCache()
         self._cache16 = PackedCache()
+        self._cache_reg = PackedCache()
 
     def output_dim(self) -> int:
         return self._label_type.dim
+
+    def _packed_reg(self):
+        """(weight stream, biases) of the register-resident conv chain, or None when it is not selected
+        (DCLR_HEAD_REG=1; off by default: measured no faster than the LDS-resident chain) or the
+        layer widths are not the reference architecture's (dclr_head_conv_reg_f16 is built for
+        259 -> 256 -> 256 -> 512 -> 512 -> 1024)."""
+        params = self.conv.affine_params()
+        if [w.shape[0] for w, _ in params] != ops.HEAD_REG_WIDTHS or any(b is None for _, b in params) \
+                or os.environ.get('DCLR_HEAD_REG', '0') != '1':
+            return None
+
+        def build():
+            dev = params[0][0].device
+            kmap = torch.full((ops.HEAD_REG_K0,), -1, dtype=torch.int32, device=dev)
+            kmap[:256] = torch.arange(3, 259, dtype=torch.int32, device=dev)       # rows E: [feat | xyz | pad]
+            kmap[256:259] = torch.arange(0, 3, dtype=torch.int32, device=dev)
+            packed = ops.head_reg_pack([w for w, _ in params], kmap)
+            return packed, torch.cat([b.detach().reshape(-1) for _, b in params]).contiguous()
+        return self._cache_reg.get(list(self.conv.parameters()), build)
+
+    def _use_reg(self, rows: int, pairs: int) -> bool:
+        return ops.PRECISION == 'f16x2' and rows % 64 == 0 and (rows // pairs) % 64 == 0 and self._packed_reg() is not None
 
     def _packed(self):
         def build():
@@ -253,7 +276,10 @@ class OutputSimple(DeepCLRModule):
     def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         layers = self._packed()
         if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
-            if ops.PRECISION == 'f16x2':
+            if self._use_reg(e_rows.shape[0], pairs):
+                packed, bias = self._packed_reg()
+                g = ops.head_conv_reg_f16(e_rows, ops.E_STRIDE, packed, bias, pairs)
+            elif ops.PRECISION == 'f16x2':
                 g = ops.head_conv_fused_f16(e_rows, ops.E_STRIDE, self._packed_f16(), pairs)
             else:
                 g = ops.head_conv_fused(e_rows, layers, pairs)               # conv chain + max over points
@@ -393,6 +419,10 @@ class _MergePlan:
         a.pt, a.ps, a.knn_idx, a.e_rows = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr(), ws['e'].data_ptr()
         a.colmax = ws['colmax'].data_ptr()
         a.fc_tmp[0], a.fc_tmp[1] = ws['tmp'][0].data_ptr(), ws['tmp'][1].data_ptr()
+        if f16 and head._use_reg(rows, pairs):
+            reg = head._packed_reg()
+            keep['tensors'].append(reg)
+            a.head_reg_w, a.head_reg_bias = reg[0].data_ptr(), reg[1].data_ptr()
         return cls(a, keep, cls._version_key(keep['mods']), pairs, fcs[-1][0].shape[0], device)
 
     def _check(self, f_rows: torch.Tensor) -> torch.Tensor:

@@ -294,6 +294,35 @@ def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torc
     return out
 
 
+HEAD_REG_WIDTHS = [256, 256, 512, 512, 1024]        # the conv chain dclr_head_conv_reg_f16 is built for
+HEAD_REG_K0 = 288
+
+
+def head_reg_pack(weights: Sequence[torch.Tensor], kmap0: torch.Tensor) -> torch.Tensor:
+    """Row-major conv weights of the five head layers -> the LDS-ring stream of dclr_head_conv_reg_f16."""
+    ws = [lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w') for w in weights]
+    assert kmap0.dtype == torch.int32 and kmap0.numel() == HEAD_REG_K0 and kmap0.is_cuda
+    nl = len(ws)
+    k_h = (ctypes.c_int * nl)(*[int(w.shape[1]) for w in ws])
+    n_h = (ctypes.c_int * nl)(*[int(w.shape[0]) for w in ws])
+    w_h = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws])
+    nbytes = lib.load().dclr_head_reg_packed_bytes()
+    packed = torch.empty(nbytes // 4, dtype=torch.int32, device=ws[0].device)
+    _call('dclr_head_reg_pack', 'head_reg_pack', nl, ctypes.cast(k_h, ctypes.c_void_p), ctypes.cast(n_h, ctypes.c_void_p),
+          ctypes.cast(w_h, ctypes.c_void_p), kmap0.data_ptr(), packed.data_ptr(), lib.stream_ptr())
+    return packed
+
+
+def head_conv_reg_f16(x: torch.Tensor, k_in: int, packed: torch.Tensor, bias: torch.Tensor, groups: int) -> torch.Tensor:
+    """x rows (m, ldx) -> (groups, 1024) column maxima through the register-resident conv chain."""
+    x = lib.dev_f32(x, 'x')
+    m, ldx = x.shape
+    out = torch.zeros(groups, HEAD_REG_WIDTHS[-1], dtype=torch.float32, device=x.device)
+    _call('dclr_head_conv_reg_f16', 'head_conv_fused[%dx%d]' % (groups, m // groups), m, int(k_in), packed.data_ptr(),
+          lib.dev_f32(bias, 'bias').data_ptr(), x.data_ptr(), ldx, out.data_ptr(), m // groups, lib.stream_ptr())
+    return out
+
+
 def flow_embedding_fused_f16(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.Tensor, ps: torch.Tensor,
                              w1a: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
                              w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:

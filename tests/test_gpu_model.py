@@ -260,7 +260,7 @@ def test_linear_kernel_against_torch():
         _close(ops.linear(x.to(DEV), wp, None, n, kp, relu=False), raw)
 
 
-def test_fused_head_chain_equals_layer_by_layer_kernels():
+def test_fused_head_chain_equals_layer_by_layer_kernels(monkeypatch):
     """Batches of >= 4 pairs run the five head layers in one launch, smaller ones layer by layer. On the f32 matrix
     instructions both use the same k order: identical results. The split-fp16 chain (default) must agree with the
     float64 product at least as well as those do."""
@@ -293,6 +293,25 @@ def test_fused_head_chain_equals_layer_by_layer_kernels():
     _close(split, want.float())
     err32, err16 = (fused.double().cpu() - want).abs().max().item(), (split.double().cpu() - want).abs().max().item()
     assert err16 <= 2 * err32 + 1e-7, (err16, err32)        # no less accurate than the f32 matrix instructions
+    # the register-resident chain (activations in registers, weights through the LDS ring; opt-in): same operator
+    monkeypatch.setenv('DCLR_HEAD_REG', '1')
+    assert head._use_reg(rows, pairs) and not head._use_reg(rows, 128)          # 32 rows per group: falls back
+    packed, bias = head._packed_reg()
+    reg = ops.head_conv_reg_f16(e, ops.E_STRIDE, packed, bias, pairs)
+    _close(reg, want.float())
+    err_reg = (reg.double().cpu() - want).abs().max().item()
+    print('head chain max abs error vs float64: f32 MFMA %.3g, split-f16 LDS form %.3g, split-f16 register form %.3g'
+          % (err32, err16, err_reg))
+    assert err_reg <= 2 * err32 + 1e-7, (err_reg, err32)
+    # every group size and row count the model can hand it: per-pair groups of 64 .. 1024 rows, ragged last workgroup wave
+    for rows2, pairs2 in ((64, 1), (128, 2), (1024, 1), (1536, 3), (8192, 8)):
+        e2 = e[:rows2].contiguous() if rows2 <= rows else torch.cat((e, e.flip(0)))[:rows2].contiguous()
+        a = ops.head_conv_reg_f16(e2, ops.E_STRIDE, packed, bias, pairs2)
+        b = ops.head_conv_fused_f16(e2, ops.E_STRIDE, head._packed_f16(), pairs2)
+        _close(a, b.cpu())
+        assert torch.equal(a, ops.head_conv_reg_f16(e2, ops.E_STRIDE, packed, bias, pairs2))     # deterministic
+    with pytest.raises(RuntimeError):
+        ops.head_conv_reg_f16(e[:96].contiguous(), ops.E_STRIDE, packed, bias, 1)                 # m % 64 != 0
 
 
 def test_full_size_kitti_batch_properties_and_oracle_pair():
