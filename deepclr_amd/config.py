@@ -90,3 +90,70 @@ def load_model_config(cfg_filename: str, weights_filename: Optional[str]) -> Con
     with open(cfg_filename, 'r') as stream:
         data = yaml.safe_load(stream)
     return model_config_from_dict(data, weights_filename)
+
+
+class Mode(ConfigEnum):
+    """Configuration modes (reference: config/utils.py:18-23)."""
+    NEW = 1
+    CONTINUE = 2
+    INFERENCE = 3
+    TEST = 4
+
+
+def _merge(base: Dict, over: Dict) -> Dict:
+    """Nested mapping update: what the reference's Config.read_dict does with a file that `extends:` another."""
+    out = dict(base)
+    for k, v in over.items():
+        out[k] = _merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+    return out
+
+
+def _read_with_extends(filename: str) -> Dict:
+    import os.path as osp
+    with open(filename, 'r') as stream:
+        data = yaml.safe_load(stream) or {}
+    parent = data.pop('extends', None)
+    if parent is not None:
+        parent = osp.realpath(osp.join(osp.dirname(filename), parent))
+        if osp.realpath(filename) != parent:                 # reference: config/utils.py:138-141
+            data = _merge(_read_with_extends(parent), data)
+    return data
+
+
+def _expand(path: Any) -> Any:
+    import os
+    if isinstance(path, (list, tuple)):
+        return [_expand(p) for p in path]
+    if isinstance(path, str):
+        return os.path.expandvars(os.path.expanduser(path))
+    return path
+
+
+def load_config(cfg_filename: str, mode: Any, ckpt_filename: Optional[str] = None) -> Config:
+    """Read a run configuration (`*.yaml`, `extends:` chains followed) the way scripts/timing.py needs it
+    (reference: config/utils.py:232-248; caller scripts/timing.py:57): `cfg.device`, `cfg.model` (finalized as by
+    load_model_config: enums created, dimensions checked) and the `data` / `data_loader` / `transforms` sections as
+    plain nested mappings for make_data_loader. What the reference's finish_config adds for TRAINING runs -- output
+    directories, the `git rev-parse` of the package checkout (which fails outside a git checkout),
+    optimizer / scheduler / metric validation, freezing -- is control plane of the training engine and not done here."""
+    mode = Mode.create(mode.name) if isinstance(mode, Enum) else Mode.create(mode)
+    data = _read_with_extends(cfg_filename)
+    if 'model' not in data:
+        raise RuntimeError("Configuration is not valid, missing required parameters.")      # reference wording
+    cfg = Config.from_dict(data)
+    cfg.mode = mode
+    cfg.extends = None
+    cfg.checkpoint = _expand(ckpt_filename if ckpt_filename is not None else cfg.get('checkpoint'))
+    if mode == Mode.CONTINUE and cfg.checkpoint is None:
+        raise RuntimeError("Please specify the checkpoint for continue")
+    cfg.device = cfg.get('device', 'cuda')
+    cfg.base_dir = _expand(cfg.get('base_dir'))
+    cfg.model = model_config_from_dict(data['model'], _expand(data['model'].get('weights')))
+    if mode == Mode.INFERENCE and cfg.model.weights is None:
+        raise RuntimeError("Please specify the model weights for inference")
+    section = cfg.get('data')
+    if isinstance(section, Config):
+        for key in ('training', 'validation'):
+            if key in section:
+                section[key] = _expand(section[key])
+    return cfg

@@ -535,6 +535,8 @@ class DeepCLR(BaseModel):
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
+        if ops.CHECK_RANGE and ops.PRECISION == 'f16x2':
+            return self._merge_rows_checked(f_rows, pairs, out)
         plan = self._merge_plan(f_rows, pairs)
         if plan is not None:
             if events is None and ops.TIMER is not None:
@@ -544,6 +546,26 @@ class DeepCLR(BaseModel):
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         y = self._merge_layers[1].forward_rows(e_rows, pairs)
         return y if out is None else out.copy_(y)
+
+    def _merge_rows_checked(self, f_rows: torch.Tensor, pairs: int, out: Optional[torch.Tensor]) -> torch.Tensor:
+        """DCLR_CHECK_RANGE=1: the dense stages on the split-f16 path AND on the f32 matrix instructions; raises when an
+        operand left the f16 range (the split path clamps at +-65504 and would return wrong poses silently)."""
+        flow, head = self._merge_layers[0], self._merge_layers[1]
+        e16 = flow.forward_rows(f_rows, pairs, self.npoint)
+        y16 = head.forward_rows(e16, pairs)
+        ops.PRECISION = 'f32'
+        try:
+            e32 = flow.forward_rows(f_rows, pairs, self.npoint)
+            y32 = head.forward_rows(e32, pairs)
+        finally:
+            ops.PRECISION = 'f16x2'
+        peak = max(float(f_rows.abs().max()), float(e32.abs().max()))
+        err = float((y16 - y32).abs().max())
+        if not (err <= 1e-4 * max(1.0, float(y32.abs().max()))) or not peak < ops.F16_MAX:
+            raise RuntimeError("split-f16 matrix path out of range: activations reach {:.4g} (limit 65504) and the pose "
+                               "outputs differ from the f32 matrix path by {:.3g}; run this checkpoint with "
+                               "DCLR_PRECISION=f32".format(peak, err))
+        return y16 if out is None else out.copy_(y16)
 
     def _merge_plan(self, f_rows: torch.Tensor, pairs: int):
         flow, head = self._merge_layers[0], self._merge_layers[1]

@@ -26,6 +26,21 @@ TIMER = None
 # halves on the f16 matrix instructions (f32-accurate, csrc/mma16f.h), 'f32' = the f32 matrix instructions.
 PRECISION = os.environ.get('DCLR_PRECISION', 'f16x2')
 
+# Split-f16 operands saturate at +-65504 (csrc/mma16f.h clamps instead of producing inf). Weights are checked when they
+# are packed; activations cannot be checked inside the fused kernels for free, so CHECK_RANGE (DCLR_CHECK_RANGE=1) makes
+# every forward ALSO run the dense stages on the f32 matrix instructions and raise if the two disagree -- a debugging
+# mode for new checkpoints, not for production throughput.
+CHECK_RANGE = os.environ.get('DCLR_CHECK_RANGE', '0') == '1'
+F16_MAX = 65504.0
+
+
+def check_f16_range(t: torch.Tensor, what: str) -> None:
+    """Raise if a tensor about to be packed as split-f16 operands leaves the f16 range (one host sync, pack time only)."""
+    peak = float(t.detach().abs().max()) if t.numel() else 0.0
+    if not peak < F16_MAX:
+        raise RuntimeError("{}: |value| reaches {:.4g}, outside the split-f16 operand range (+-65504); run with "
+                           "DCLR_PRECISION=f32 (f32 matrix instructions) for this checkpoint".format(what, peak))
+
 
 
 def _call(name: str, what: str, *args) -> None:
@@ -268,6 +283,7 @@ def head_conv_fused(x: torch.Tensor, layers, groups: int) -> torch.Tensor:
 def pack_weight_f16(w: torch.Tensor, kp: int, width: int, kmap: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row-major (n_out, k_in) -> split-fp16 fragments (hi plane | lo plane) for `width`-column MFMA tiles."""
     w = lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w')
+    check_f16_range(w, 'pack_weight_f16')
     n_out, k_in = w.shape
     np_ = (n_out + width - 1) // width * width
     packed = torch.empty(np_ * kp, dtype=torch.float32, device=w.device)          # 2 planes of np*kp halves
@@ -301,6 +317,8 @@ HEAD_REG_K0 = 288
 def head_reg_pack(weights: Sequence[torch.Tensor], kmap0: torch.Tensor) -> torch.Tensor:
     """Row-major conv weights of the five head layers -> the LDS-ring stream of dclr_head_conv_reg_f16."""
     ws = [lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w') for w in weights]
+    for w in ws:
+        check_f16_range(w, 'head_reg_pack')
     assert kmap0.dtype == torch.int32 and kmap0.numel() == HEAD_REG_K0 and kmap0.is_cuda
     nl = len(ws)
     k_h = (ctypes.c_int * nl)(*[int(w.shape[1]) for w in ws])

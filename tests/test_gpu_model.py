@@ -3,6 +3,8 @@
 Tolerances: indices/counts exact; activations rtol 1e-4 / atol 1e-5 against fp32 CPU (the MFMA
 kernels are exact fp32 fmaf chains, only the summation order differs from the CPU GEMMs); pose
 4x4 within 1e-4 absolute (BASELINE.json's stated tolerance)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -30,9 +32,28 @@ def _mats(y):
     return np.stack([LabelType.POSE3D_DUAL_QUAT.to_matrix(v) for v in y.detach().cpu().numpy()])
 
 
-def _close(got: torch.Tensor, want, rtol=RTOL, atol=ATOL):
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_errors.txt')
+
+
+def _close(got: torch.Tensor, want, rtol=RTOL, atol=ATOL, stage=None):
+    """assert_close with the tolerances of the module header; with `stage` the measured error is also printed and
+    appended to gpurun_out/parity_errors.txt (max |got - want|, the same relative to max |want|, and the largest
+    elementwise relative error among elements above 1e-3 of the scale)."""
     want = torch.as_tensor(want)
     scale = max(1.0, float(want.abs().max()))
+    if stage is not None:
+        g, w = got.detach().cpu().double(), want.double()
+        err = (g - w).abs()
+        big = w.abs() > 1e-3 * scale
+        rel = float((err[big] / w.abs()[big]).max()) if bool(big.any()) else 0.0
+        line = '%-58s max abs %.3e  (/scale %.3e)  max rel %.3e  scale %.3g' % (stage, float(err.max()), float(err.max()) / scale, rel, scale)
+        print(line)
+        try:
+            os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+            with open(PARITY_LOG, 'a') as fh:
+                fh.write(line + '\n')
+        except OSError:
+            pass
     torch.testing.assert_close(got.detach().cpu(), want, rtol=rtol, atol=atol * scale)
 
 
@@ -51,18 +72,20 @@ def test_model_matches_golden_and_oracle(name):
     assert torch.equal(feat[:, :3, :].cpu(), torch.from_numpy(g['x'])[:, :, :3].gather(
         1, torch.from_numpy(g['fps_idx'].astype(np.int64))[:, :, None].expand(-1, -1, 3)).transpose(1, 2))
     if GOLDEN_CASES[name][1]:
-        _close(feat, g['cloud_features'])
-        _close(emb, g['flow_embedding'])
+        _close(feat, g['cloud_features'], stage=name + ': cloud_features vs reference golden')
+        _close(emb, g['flow_embedding'], stage=name + ': flow_embedding vs reference golden')
     else:
         for key, t in (('cloud_features', feat), ('flow_embedding', emb)):
             assert tuple(t.shape) == tuple(g[key + '_shape'])
             got = t.contiguous().view(-1)[torch.from_numpy(g[key + '_pos']).to(DEV)]
-            _close(got, g[key + '_val'])
-    _close(y, g['y'])
-    _close(y_feat, g['y'])
-    assert np.abs(_mats(y) - g['mat']).max() < 1e-4
+            _close(got, g[key + '_val'], stage=name + ': ' + key + ' (sampled) vs reference golden')
+    _close(y, g['y'], stage=name + ': y (B, 8) vs reference golden')
+    _close(y_feat, g['y'], stage=name + ': y via is_feat=True vs reference golden')
+    mat_err = float(np.abs(_mats(y) - g['mat']).max())
+    _close(torch.from_numpy(_mats(y)).float(), g['mat'].astype(np.float32), rtol=0, atol=1e-4, stage=name + ': 4x4 pose vs reference golden')
+    assert mat_err < 1e-4
     # and against the oracle recomputed on this host
-    _close(y, orc(torch.from_numpy(g['x'])))
+    _close(y, orc(torch.from_numpy(g['x'])), stage=name + ': y vs oracle on this host')
 
 
 @pytest.mark.parametrize('kind,n,pairs', [('kitti', 4096, 2), ('modelnet', 2048, 3)])
@@ -93,7 +116,7 @@ def test_fused_stages_against_oracle(kind, n, pairs):
     feat_o = orc.cloud_features(x_cpu)
     with torch.no_grad():
         feat = model.cloud_features(x.clone())
-    _close(feat, feat_o)
+    _close(feat, feat_o, stage='%s n=%d: cloud_features vs oracle' % (kind, n))
 
     # kNN on the oracle's features (identical xyz) : exact neighbour lists
     f_rows = ops.channels_to_rows(feat_o.to(DEV).contiguous(), ops.F_STRIDE)
@@ -106,12 +129,12 @@ def test_fused_stages_against_oracle(kind, n, pairs):
     with torch.no_grad():
         emb = model._merge_layers[0](feat_o.to(DEV))
         emb_o = orc.flow_embedding(feat_o)
-        _close(emb, emb_o)
+        _close(emb, emb_o, stage='%s n=%d: flow_embedding vs oracle (oracle features in)' % (kind, n))
         y = model._merge_layers[1](emb_o.to(DEV))
-        _close(y, orc.pose_head(emb_o))
+        _close(y, orc.pose_head(emb_o), stage='%s n=%d: pose head vs oracle (oracle embedding in)' % (kind, n))
         y_full, _, _ = model(x.clone())
     y_o = orc(x_cpu)
-    _close(y_full, y_o)
+    _close(y_full, y_o, stage='%s n=%d: y end to end vs oracle' % (kind, n))
     mats_o = np.stack([olabels.dual_quat_to_matrix(v) for v in y_o.numpy()])
     assert pose_delta(_mats(y_full), mats_o) < 1e-4
 
@@ -527,6 +550,124 @@ def test_flow_embedding_split_fp16_against_f32_path_and_float64(k, radius):
     err16 = (e16[:, :256].double() - want).abs().max().item()
     _close(e16[:, :256], want.float().cpu())
     assert err16 <= 2 * err32 + 1e-7, (err16, err32)
+
+
+def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_oracle():
+    """`forward(x, m=m)` / `cloud_features(x, m)`: the homogeneous transforms m (2B, 4, 4) are applied to the point
+    columns of x IN PLACE before set abstraction (reference: deepclr.py:512-514, tgm.transform_points(m, x[:, :, :3]));
+    the outputs are then those of the plain forward on the transformed clouds (checked against the oracle)."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=17)
+    model, orc = _models(cfg, sd)
+    pairs, n = 2, 2048
+    x_cpu = torch.from_numpy(synthetic.make_batch('kitti', pairs, n, first_pair=70))
+    rng = np.random.default_rng(5)
+    m = np.tile(np.eye(4, dtype=np.float32), (2 * pairs, 1, 1))
+    for i in range(2 * pairs):
+        m[i, :3, :3] = synthetic._euler_to_mat(*np.deg2rad(rng.uniform(-20, 20, size=3))).astype(np.float32)
+        m[i, :3, 3] = rng.uniform(-2, 2, size=3).astype(np.float32)
+    m_t = torch.from_numpy(m)
+    want_x = x_cpu.clone()
+    want_x[:, :, :3] = (x_cpu[:, :, :3].double() @ m_t[:, :3, :3].double().transpose(1, 2) + m_t[:, None, :3, 3].double()).float()
+    for entry in ('forward', 'cloud_features'):
+        x = x_cpu.clone().to(DEV)
+        with torch.no_grad():
+            if entry == 'forward':
+                y, _, _ = model(x, m=m_t.to(DEV))
+            else:
+                feat = model.cloud_features(x, m_t.to(DEV))
+        moved = x.cpu()
+        assert torch.equal(moved[:, :, 3:], x_cpu[:, :, 3:])                      # feature columns untouched
+        _close(moved[:, :, :3], want_x[:, :, :3], rtol=1e-5, atol=1e-6, stage='m path: transformed points vs float64 transform')
+        assert not torch.equal(moved[:, :, :3], x_cpu[:, :, :3])                  # ... and it did happen in place
+        if entry == 'forward':
+            _close(y, orc(moved), stage='m path: y vs oracle on the transformed clouds')
+            y_feat, _, _ = model(model.cloud_features(moved.to(DEV)), is_feat=True, m=m_t.to(DEV))   # m is ignored with is_feat
+            assert torch.equal(y_feat, y)
+        else:
+            _close(feat, orc.cloud_features(moved), stage='m path: cloud_features vs oracle on the transformed clouds')
+
+
+def test_split_f16_range_guard(monkeypatch):
+    """The default matrix path carries operands as f16 hi/lo halves and clamps at +-65504 (csrc/mma16f.h). Weights out
+    of range are refused when they are packed; activations out of range are caught by the checked mode
+    (ops.CHECK_RANGE / DCLR_CHECK_RANGE=1), which reruns the dense stages on the f32 matrix instructions; and the f32
+    path itself (DCLR_PRECISION=f32) still agrees with the oracle on such a checkpoint."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=9)
+    x_cpu = torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=90))
+    # in range: the checked mode passes and returns exactly what the unchecked forward returns
+    model, orc = _models(cfg, sd)
+    with torch.no_grad():
+        y_plain, _, _ = model(x_cpu.to(DEV))
+        monkeypatch.setattr(ops, 'CHECK_RANGE', True)
+        y_checked, _, _ = model(x_cpu.to(DEV))
+        monkeypatch.setattr(ops, 'CHECK_RANGE', False)
+    _close(y_checked, y_plain.cpu(), stage='checked mode vs plain forward (in range)')
+    # activations out of range: the last flow-embedding layer scaled so that rows E reach ~1e6
+    big = {k: v.clone() for k, v in sd.items()}
+    big['_merge_layers.0._embedding._conv._sequential.2._sequential.0.weight'] *= 3.0e5
+    big['_merge_layers.1.conv._sequential.0._sequential.0.weight'] *= 1.0 / 3.0e5          # keeps the head in range
+    model_big, orc_big = _models(cfg, big)
+    y_o = orc_big(x_cpu)
+    with torch.no_grad():
+        y16, _, _ = model_big(x_cpu.to(DEV))                                               # silently clamped ...
+        assert float((y16.cpu() - y_o).abs().max()) > 1e-3                                 # ... and therefore wrong
+        monkeypatch.setattr(ops, 'CHECK_RANGE', True)
+        with pytest.raises(RuntimeError, match='split-f16 matrix path out of range'):
+            model_big(x_cpu.to(DEV))
+        monkeypatch.setattr(ops, 'CHECK_RANGE', False)
+        monkeypatch.setattr(ops, 'PRECISION', 'f32')
+        y32, _, _ = model_big(x_cpu.to(DEV))
+    _close(y32, y_o, stage='f32 matrix path vs oracle, activations ~1e6')
+    monkeypatch.setattr(ops, 'PRECISION', 'f16x2')
+    # weights out of range: refused at pack time
+    huge = {k: v.clone() for k, v in sd.items()}
+    huge['_merge_layers.1.conv._sequential.2._sequential.0.weight'][0, 0, 0] = 7.0e4
+    model_huge, _ = _models(cfg, huge)
+    with pytest.raises(RuntimeError, match='outside the split-f16 operand range'):
+        with torch.no_grad():
+            model_huge(x_cpu.to(DEV))
+
+
+def test_timing_script_call_sequence_runs_on_the_hip_path():
+    """The body of the reference's scripts/timing.py (lines 13-47), statement for statement, against this package
+    under the reference's import names: load_config -> build_model -> model.to(cfg.device) -> ModelInferenceHelper ->
+    make_data_loader(cfg, is_train=False, batch_size=1) -> prepare_tensor -> predict between two CUDA events."""
+    from deepclr.config import load_config, Mode
+    from deepclr.data import make_data_loader
+    from deepclr.models import build_model as ref_build_model, ModelInferenceHelper as RefHelper
+    from deepclr.utils.logging import create_logger
+    from deepclr.utils.tensor import prepare_tensor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, 'configs', 'timing_synthetic_kitti.yaml'), Mode.TEST)
+    create_logger(name='timing')
+    for sequential in (False, True):
+        model = ref_build_model(cfg.model)
+        model.to(cfg.device)
+        model.eval()
+        helper = RefHelper(model, is_sequential=sequential)
+        data_loader = make_data_loader(cfg, is_train=False, batch_size=1)
+        times, outs = [], []
+        for i, batch in enumerate(data_loader):
+            if i == 4:
+                break
+            x = prepare_tensor(batch['x'], device=cfg.device)
+            template, source = x[0, ...], x[1, ...]
+            t_start, t_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_start.record()
+            if sequential:
+                if not helper.has_state():
+                    helper.predict(template)
+                y = helper.predict(source)
+            else:
+                y = helper.predict(source, template)
+            t_end.record()
+            torch.cuda.synchronize()
+            times.append(t_start.elapsed_time(t_end))
+            outs.append(y)
+        assert all(t > 0 for t in times) and all(tuple(o.shape) == (8,) and bool(torch.isfinite(o).all()) for o in outs)
+        print('timing.py sequence (sequential=%s): %s ms per pair' % (sequential, ['%.2f' % t for t in times]))
 
 
 def test_forward_with_labels_returns_the_configured_loss():

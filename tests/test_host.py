@@ -133,8 +133,6 @@ def test_reference_import_names_resolve_to_this_package(tmp_path):
     assert ModelInferenceHelper is deepclr_amd.models.ModelInferenceHelper
     with pytest.raises(RuntimeError):
         create_input_dataflow('kitti_odometry_velodyne', 'x.lmdb', shuffle=False)
-    with pytest.raises(RuntimeError):
-        load_config('cfg.yaml', Mode.TEST)
     assert prepare_tensor(torch.ones(2), device='cpu').device.type == 'cpu'
     log = create_logger('test_host_logger')
     assert log is create_logger('test_host_logger') and len(log.handlers) <= 1     # never attached twice
@@ -153,6 +151,58 @@ def test_reference_import_names_resolve_to_this_package(tmp_path):
     with pytest.raises(RuntimeError):
         load_scenario(str(scen), with_method=True)
     assert isinstance(Evaluator(), deepclr_amd.evaluation.Evaluator)
+
+
+def test_load_config_and_tensor_backed_loader_for_timing_script(tmp_path):
+    """scripts/timing.py:57 `load_config(args.config, Mode.TEST)` and :23 `make_data_loader(cfg, is_train=False,
+    batch_size=1)`: `extends:` chains, finalized model section, device, and batches in the reference's layout
+    (data/build.py:62-98). Dataset types that need the LMDB / dataflow readers raise."""
+    from deepclr.config import load_config, Mode
+    from deepclr.data import make_data_loader
+    from deepclr.models import build_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_config(os.path.join(root, 'configs', 'timing_synthetic_kitti.yaml'), Mode.TEST)
+    assert cfg.device == 'cuda' and cfg.mode == Mode.TEST and cfg.extends is None
+    assert cfg.model.label_type.name == 'POSE3D_DUAL_QUAT' and cfg.model.model_type.name == 'DEEPCLR'
+    assert cfg.model.params.cloud_features.params.npoint == [1024] and cfg.model.params.merge.params.k == 20
+    model = build_model(cfg.model)                                       # timing.py:15
+    assert sum(p.numel() for p in model.parameters()) == 1778312
+    loader = make_data_loader(cfg, is_train=False, batch_size=1)         # timing.py:23
+    batches = list(loader)
+    assert len(batches) == len(loader) == 32
+    b = batches[3]
+    assert tuple(b['x'].shape) == (2, 16384, 4) and b['x'].dtype == torch.float32
+    assert tuple(b['y'].shape) == (1, 8) and tuple(b['m'].shape) == (2, 4, 4) and tuple(b['t'].shape) == (1, 2)
+    np.testing.assert_allclose(cfg.model.label_type.to_matrix(b['y'][0].numpy().copy()),
+                               synthetic.kitti_like_pair(100003, 16384)[2], atol=1e-6)
+    again = list(make_data_loader(cfg, is_train=False, batch_size=1))
+    assert torch.equal(b['x'], again[3]['x'])                             # seeded: the same pairs every time
+    big = make_data_loader(cfg, is_train=True, batch_size=5)
+    first = next(iter(big))
+    assert tuple(first['x'].shape) == (10, 16384, 4) and len(big) == 7
+    # a child file overrides its parent section by section; environment variables in paths are expanded
+    child = tmp_path / 'child.yaml'
+    child.write_text("extends: '%s'\ndevice: cuda:1\nbase_dir: '${HOME}/runs'\n"
+                     "data:\n  dataset_type: kitti_odometry_velodyne\n  validation: ['${HOME}/odometry/07.lmdb']\n"
+                     "model:\n  params:\n    merge:\n      params:\n        k: 16\n"
+                     % os.path.join(root, 'configs', 'timing_synthetic_kitti.yaml'))
+    cfg2 = load_config(str(child), Mode.TEST)
+    assert cfg2.device == 'cuda:1' and '$' not in cfg2.base_dir and '$' not in cfg2.data.validation[0]
+    assert cfg2.model.params.merge.params.k == 16 and cfg2.model.params.merge.params.radius == 10.0
+    assert cfg2.data.points == 16384                                      # inherited
+    with pytest.raises(RuntimeError, match='LMDB'):
+        make_data_loader(cfg2, is_train=False, batch_size=1)
+    with pytest.raises(RuntimeError, match='checkpoint'):
+        load_config(str(child), Mode.CONTINUE)
+    nomodel = tmp_path / 'nomodel.yaml'
+    nomodel.write_text("device: cuda\n")
+    with pytest.raises(RuntimeError, match='missing required parameters'):
+        load_config(str(nomodel), Mode.TEST)
+    ref = '/root/reference/configs/training/kitti_00-06.yaml'              # the reference's own files, where present
+    if os.path.exists(ref):
+        cfg3 = load_config(ref, Mode.TEST)
+        assert cfg3.identifier == 'kitti_00-06' and cfg3.model.input_dim == 4 and cfg3.data_loader.batch_size == 5
+        assert cfg3.model.params.output.params.mlp == [256, 256, 512, 512, 1024]
 
 
 def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
