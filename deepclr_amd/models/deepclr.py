@@ -94,14 +94,13 @@ class SetAbstraction(DeepCLRModule):
 # flow embedding
 # --------------------------------------------------------------------------------------------------
 class MotionEmbeddingBase(nn.Module):
-    """kNN grouping + shared MLP + radius mask + max (reference: deepclr.py:176-231)."""
+    """kNN grouping (or, with k == 0, GlobalGrouping: every point of the pair's source cloud, reference
+    deepclr.py:108-139,186-187) + shared MLP + radius mask + max (reference: deepclr.py:176-231)."""
 
     def __init__(self, input_dim: int, point_dim: int, k: int, radius: float, mlp: List[int],
                  append_features: bool = True, batch_norm: bool = False, **_kwargs: Any):
         super().__init__()
-        if k == 0:
-            raise NotImplementedError("global grouping (k == 0) is not used by any shipped model")
-        if not 1 <= k <= 32:
+        if not 0 <= k <= 32:
             raise NotImplementedError("the fused flow-embedding kernel pads each neighbourhood to 32 rows (k <= 32)")
         if list(mlp) != [128, 128, 256]:
             raise NotImplementedError("the fused flow-embedding kernel is built for mlp [128, 128, 256]")
@@ -145,12 +144,29 @@ class MotionEmbeddingBase(nn.Module):
         half = pairs * npoint
         pt = ops.linear(f_rows[:half], p['wt'], None, 128, FEAT, relu=False)
         ps = ops.linear(f_rows[half:], p['ws'], None, 128, FEAT, relu=False)
-        knn_idx = ops.knn_rows(f_rows, pairs, npoint, self._k)
-        if ops.PRECISION == 'f16x2':
-            return ops.flow_embedding_fused_f16(f_rows, knn_idx, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'],
-                                                p['w3h'], p['b3'], self._radius)
-        return ops.flow_embedding_fused(f_rows, knn_idx, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'],
-                                        p['w3p'], p['b3'], self._radius)
+
+        def embed(idx):
+            if ops.PRECISION == 'f16x2':
+                return ops.flow_embedding_fused_f16(f_rows, idx, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'],
+                                                    p['w3h'], p['b3'], self._radius)
+            return ops.flow_embedding_fused(f_rows, idx, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'],
+                                            p['w3p'], p['b3'], self._radius)
+        if self._k > 0:
+            return embed(ops.knn_rows(f_rows, pairs, npoint, self._k))
+        # GlobalGrouping: the neighbourhood of every template point is the whole source cloud of its pair. The fused
+        # kernel takes up to 32 neighbours per point; the maximum over all of them is the maximum over 32-point slices
+        # of the maxima within each (post-ReLU values and the 0 of radius-masked rows: the same floor in every slice).
+        e_rows = None
+        for j0 in range(0, npoint, 32):
+            kc = min(32, npoint - j0)
+            idx = torch.arange(j0, j0 + kc, dtype=torch.int32, device=f_rows.device).view(1, 1, kc) \
+                .expand(pairs, npoint, kc).contiguous()
+            part = embed(idx)
+            if e_rows is None:
+                e_rows = part
+            else:
+                torch.maximum(e_rows[:, :256], part[:, :256], out=e_rows[:, :256])
+        return e_rows
 
     def forward(self, clouds0: torch.Tensor, clouds1: torch.Tensor) -> torch.Tensor:
         """(B, 3+F, P) template / source feature clouds -> (B, 3+256, P), as the reference module."""
@@ -386,8 +402,8 @@ class _MergePlan:
         rows = pairs * npoint
         f16 = ops.PRECISION == 'f16x2'
         layers = head._packed_f16() if f16 else head._packed()
-        if not head._fusable(head._packed(), rows, pairs) or (not f16 and rows < 4096):
-            return None
+        if not head._fusable(head._packed(), rows, pairs) or (not f16 and rows < 4096) or flow._k == 0:
+            return None                             # (GlobalGrouping runs slice by slice through forward_rows)
         fcs = [(m.affine.weight, m.affine.bias, 1) for m in head.linear.layers()]
         fcs.append((head.output.weight, head.output.bias, head._act))
         if len(layers) > lib.MERGE_MAX_LAYERS or len(fcs) > lib.MERGE_MAX_FC or any(b is None for _, b, _ in fcs):

@@ -144,11 +144,20 @@ class OracleDeepCLR:
 
     # -- deepclr.py:201-231, 243-246 ------------------------------------------------------------
     def flow_embedding(self, clouds: torch.Tensor) -> torch.Tensor:
-        assert self.k > 0, "GlobalGrouping (k == 0) is not used by any shipped config"
         half = clouds.shape[0] // 2
         c0, c1 = clouds[:half], clouds[half:]
-        pts0, pts1, gi = self.knn_groups(c0, c1)
-        g0, g1 = pts0[gi[0]], pts1[gi[1]]
+        if self.k == 0:
+            # GlobalGrouping (deepclr.py:108-139, selected at 186-187): every template point is grouped with ALL points
+            # of its pair's source cloud, in index order
+            pts0 = c0.transpose(1, 2).contiguous().view(-1, c0.shape[1])
+            pts1 = c1.transpose(1, 2).contiguous().view(-1, c1.shape[1])
+            p0, p1 = c0.shape[2], c1.shape[2]
+            idx0 = torch.arange(pts0.shape[0]).view(-1, 1).repeat(1, p1)
+            idx1 = torch.arange(pts1.shape[0]).view(c1.shape[0], -1).repeat(1, p0).view(idx0.shape)
+            g0, g1 = pts0[idx0], pts1[idx1]
+        else:
+            pts0, pts1, gi = self.knn_groups(c0, c1)
+            g0, g1 = pts0[gi[0]], pts1[gi[1]]
         d = self.point_dim
         pos_diff = g1[:, :, :d] - g0[:, :, :d]
         if self.append_features:

@@ -156,6 +156,13 @@ def degenerate_batch(n_pairs: int, n_points: int, c: int, seed: int) -> np.ndarr
     return x
 
 
+def small_global_cfg() -> dict:
+    """k == 0: GlobalGrouping instead of kNN (reference: deepclr.py:186-187), on the reduced sizes."""
+    cfg = small_cfg()
+    cfg['params']['merge']['params'].update(k=0, radius=6.0)
+    return cfg
+
+
 CASES = [
     # name,              cfg factory,                        batch factory,                              weight seed, full
     ('small_kitti_n512_b2', small_cfg, lambda: synthetic.make_batch('kitti', 2, 512), 11, True),
@@ -163,6 +170,7 @@ CASES = [
     ('kitti_n2048_b1', lambda: synthetic.model_cfg('kitti'), lambda: synthetic.make_batch('kitti', 1, 2048), 13, False),
     ('modelnet_n1024_b1', lambda: synthetic.model_cfg('modelnet'),
      lambda: synthetic.make_batch('modelnet', 1, 1024), 14, False),
+    ('small_global_n256_b2', small_global_cfg, lambda: synthetic.make_batch('kitti', 2, 256, first_pair=7), 15, True),
 ]
 
 
@@ -199,10 +207,13 @@ def run_case(ref, name, cfg, x_np, wseed, full):
     assert torch.equal(new_xyz.transpose(1, 2), feat_ref[:, :3, :])
     bq = [oracle.ball_query(r, s, xyz, new_xyz) for r, s in zip(sa['radii'][0], sa['nsamples'][0])]
     half = feat_ref.shape[0] // 2
-    _, _, gi = orc.knn_groups(feat_ref[:half], feat_ref[half:])
     npoint = feat_ref.shape[2]
-    knn_local = (gi[1] - (torch.arange(half).repeat_interleave(npoint) * npoint).view(-1, 1)).to(torch.int32)
-    knn_local = knn_local.view(half, npoint, -1)
+    if cfg['params']['merge']['params']['k'] > 0:
+        _, _, gi = orc.knn_groups(feat_ref[:half], feat_ref[half:])
+        knn_local = (gi[1] - (torch.arange(half).repeat_interleave(npoint) * npoint).view(-1, 1)).to(torch.int32)
+        knn_local = knn_local.view(half, npoint, -1)
+    else:                                        # GlobalGrouping: every source point of the pair, in index order
+        knn_local = torch.arange(npoint, dtype=torch.int32).view(1, 1, -1).expand(half, npoint, -1).contiguous()
 
     out = {
         'x': x_np, 'weight_seed': np.int64(wseed), 'fps_idx': fps_idx.numpy().astype(np.int16),
@@ -230,14 +241,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference', default='/root/reference')
     ap.add_argument('--only-losses', action='store_true', help='regenerate losses.npz only')
+    ap.add_argument('--only', default=None, help='regenerate one case only')
     args = ap.parse_args()
     torch.set_num_threads(8)
     ref = _load_reference(args.reference)
-    loss_golden(ref, HERE)
+    if args.only is None:
+        loss_golden(ref, HERE)
     if args.only_losses:
         return
     for name, cfg_fn, x_fn, wseed, full in CASES:
-        run_case(ref, name, cfg_fn(), x_fn(), wseed, full)
+        if args.only is None or args.only == name:
+            run_case(ref, name, cfg_fn(), x_fn(), wseed, full)
 
 
 if __name__ == '__main__':

@@ -15,6 +15,7 @@ GOLDEN_CASES = {
     'kitti_rand_n96_b2': ('kitti', False),
     'kitti_n2048_b1': ('kitti', False),
     'modelnet_n1024_b1': ('modelnet', False),
+    'small_global_n256_b2': ('small_global', True),      # k == 0: GlobalGrouping
 }
 
 
@@ -27,8 +28,16 @@ def small_cfg() -> dict:
     return cfg
 
 
+def small_global_cfg() -> dict:
+    cfg = small_cfg()
+    cfg['params']['merge']['params'].update(k=0, radius=6.0)
+    return cfg
+
+
 def case_cfg(name: str) -> dict:
     kind = GOLDEN_CASES[name][0]
+    if kind == 'small_global':
+        return small_global_cfg()
     return small_cfg() if kind == 'small' else synthetic.model_cfg(kind)
 
 

@@ -1,8 +1,10 @@
 """GPU parity, level 2: the fused forward path against the CPU oracle and the committed goldens.
 
-Tolerances: indices/counts exact; activations rtol 1e-4 / atol 1e-5 against fp32 CPU (the MFMA
-kernels are exact fp32 fmaf chains, only the summation order differs from the CPU GEMMs); pose
-4x4 within 1e-4 absolute (BASELINE.json's stated tolerance)."""
+Tolerances: indices/counts exact; activations rtol 1e-5 / atol 1e-6 x max|want| against fp32 CPU (SURVEY.md
+section 8c; the matrix products accumulate in f32, only the summation order differs from the CPU GEMMs); pose
+4x4 within 1e-4 absolute (BASELINE.json's stated tolerance). Measured on MI355X (profiles/r02_parity_errors.txt,
+written by the `stage=` calls below): max |error| / scale <= 1.2e-6 and elementwise relative error <= 4.2e-5 on
+every stage against the reference-generated goldens and the oracle."""
 import os
 
 import numpy as np
@@ -19,7 +21,7 @@ from helpers import GOLDEN_CASES, load_golden, case_cfg, degenerate_batch, pose_
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-RTOL, ATOL = 1e-4, 1e-5
+RTOL, ATOL = 1e-5, 1e-6
 
 
 def _models(cfg: dict, sd):

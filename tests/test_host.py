@@ -69,7 +69,6 @@ def test_load_model_config_and_trained_model(tmp_path):
 def test_unsupported_configurations_fail_loudly():
     base = synthetic.model_cfg('kitti')
     for mutate in (lambda c: c['params'].update(batch_norm=True),
-                   lambda c: c['params']['merge']['params'].update(k=0),
                    lambda c: c['params']['merge']['params'].update(k=40),
                    lambda c: c['params']['merge']['params'].update(mlp=[64, 64, 128]),
                    lambda c: c['params']['cloud_features']['params'].update(mlps=[[[32, 32, 64], [16, 16, 32]]])):
@@ -78,6 +77,9 @@ def test_unsupported_configurations_fail_loudly():
         with pytest.raises(NotImplementedError):
             build_model(model_config_from_dict(cfg))
     assert base == synthetic.model_cfg('kitti')
+    cfg = synthetic.model_cfg('kitti')
+    cfg['params']['merge']['params'].update(k=0)                  # GlobalGrouping (deepclr.py:186-187) is supported
+    assert build_model(model_config_from_dict(cfg)) is not None
 
 
 def test_no_cpu_fallback():
