@@ -382,6 +382,16 @@ def _init_loss(cfg: Config, label_type: LabelType, **kwargs: Any) -> DeepCLRLoss
 
 # --------------------------------------------------------------------------------------------------
 # network
+class _Prep(tuple):
+    """(pt, ps, knn_idx) of one stage-1 run, out of a plan's small ring. `done`: event the consumer records once the
+    stage-2 launches that read the buffers are enqueued; the plan waits for it before it hands the slot out again."""
+    done: Optional[torch.cuda.Event] = None
+
+    def release(self) -> None:
+        self.done = torch.cuda.Event()
+        self.done.record()
+
+
 class _MergePlan:
     """Arguments + workspace of dclr_merge_forward for one (device, pairs, npoint, matrix path): built once,
     reused by every batch of that shape (the workspace belongs to the stream the calls are enqueued on)."""
@@ -389,6 +399,7 @@ class _MergePlan:
     def __init__(self, args, keep, versions, pairs: int, n_out: int, device):
         self.args, self._keep, self._versions = args, keep, versions
         self._pairs, self._n_out, self._device = pairs, n_out, device
+        self._ring, self._next = [], 0
 
     @staticmethod
     def _version_key(mods):
@@ -441,6 +452,8 @@ class _MergePlan:
             a.head_reg_w, a.head_reg_bias = reg[0].data_ptr(), reg[1].data_ptr()
         return cls(a, keep, cls._version_key(keep['mods']), pairs, fcs[-1][0].shape[0], device)
 
+    PREP_RING = 3
+
     def _check(self, f_rows: torch.Tensor) -> torch.Tensor:
         f_rows = lib.dev_f32(f_rows, 'f_rows')
         if f_rows.shape != (2 * self._pairs * self.args.npoint, ops.F_STRIDE):
@@ -451,8 +464,22 @@ class _MergePlan:
         """Stage 1 alone (layer-1 halves + kNN) into buffers of its own -- what a side stream can run ahead."""
         f_rows = self._check(f_rows)
         rows, a = self._pairs * self.args.npoint, self.args
-        out = (torch.empty(rows, 128, device=self._device), torch.empty(rows, 128, device=self._device),
-               torch.empty(self._pairs, a.npoint, a.k, dtype=torch.int32, device=self._device))
+        # a ring of PREP_RING buffer sets instead of three allocations per batch (a long run otherwise parks gigabytes
+        # in the caching allocator behind record_stream): a slot is reused only after its consumer released it
+        if len(self._ring) < self.PREP_RING:
+            out = _Prep((torch.empty(rows, 128, device=self._device), torch.empty(rows, 128, device=self._device),
+                         torch.empty(self._pairs, a.npoint, a.k, dtype=torch.int32, device=self._device)))
+            self._ring.append(out)
+        else:
+            old = self._ring[self._next]
+            if old.done is None:                        # never released by its consumer: leave it alone, take fresh memory
+                out = _Prep((torch.empty(rows, 128, device=self._device), torch.empty(rows, 128, device=self._device),
+                             torch.empty(self._pairs, a.npoint, a.k, dtype=torch.int32, device=self._device)))
+            else:
+                torch.cuda.current_stream().wait_event(old.done)
+                out = _Prep(tuple(old))
+            self._ring[self._next] = out
+            self._next = (self._next + 1) % self.PREP_RING
         ws = self._keep['ws']
         a.f_rows, a.stages = f_rows.data_ptr(), 1
         a.pt, a.ps, a.knn_idx = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()

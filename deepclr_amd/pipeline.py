@@ -151,6 +151,8 @@ class PipelinedForward:
             whole = out is not None and out.shape[0] == want
             with torch.no_grad():
                 y_all = self._model.merge_rows(rows, want, prep=prep, out=out if whole else None)
+            if hasattr(prep, 'release'):
+                prep.release()                               # its buffers may be reused once these launches are through
             self._group_out = (list(xs[1:]), y_all)
             y = y_all[:pairs]
             return y if (out is None or whole) else out.copy_(y)
@@ -182,7 +184,10 @@ class PipelinedForward:
                 yield from PipelinedForward._tensors(o)
 
     def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None, out=None) -> torch.Tensor:
-        return self._model.merge_rows(f_rows, x.shape[0] // 2, prep=prep, out=out)
+        y = self._model.merge_rows(f_rows, x.shape[0] // 2, prep=prep, out=out)
+        if hasattr(prep, 'release'):
+            prep.release()                                   # its buffers may be reused once these launches are through
+        return y
 
     def run(self, batches: Iterable[torch.Tensor]) -> Iterator[torch.Tensor]:
         it = iter(batches)
