@@ -8,6 +8,8 @@
 //           split and stored in place as half-octets of layer 3's input;
 //   layer 3 computes H2 * W3^T -- lane = channel, lane-quarter = template point, registers = its 4
 //           neighbours of the tile, so mask + max over the k neighbours stays in registers.
+#include <stdlib.h>
+
 #include "mma16f.h"
 
 namespace {
@@ -19,7 +21,9 @@ constexpr int F16_STRIDE = dclr_split_stride(F16_C);    // 528 bytes per row
 constexpr int F16_KG = F16_C / 32;              // 4 k-steps of 32
 
 // One pass over K for T row tiles x 2 channel tiles. TRANSPOSED: weights are the A operand.
-template <int T, bool TRANSPOSED>
+// ABL (timing-only ablations, results wrong): bit 0 = no gather round trips in phase A (rows built from constants),
+// bit 1 = weight fragments always from k-step 0 of tile 0 (no weight streaming), bit 2 = no phase A at all
+template <int T, bool TRANSPOSED, int ABL = 0>
 __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4 (&acc2)[T][2], const char *a_lane,
                                              const float4 *wh_lane, const float4 *wl_lane, int tile_stride) {
     dclr_h8 h0[2], l0[2], h1[2], l1[2];
@@ -48,16 +52,22 @@ __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4
     for (int g = 0; g < F16_KG; g += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if constexpr (ABL & 2) { h1[u] = l0[u]; l1[u] = h0[u]; }
+            else {
             h1[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
             l1[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         step(g, h0, l0);
         if (g + 2 < F16_KG) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if constexpr (ABL & 2) { h0[u] = l1[u]; l0[u] = h1[u]; }
+                else {
                 h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
                 l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -65,7 +75,7 @@ __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4
     }
 }
 
-template <int T>
+template <int T, int ABL = 0>
 __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, int npoint, int k, float radius,
                                                      const float *__restrict__ f_rows,
                                                      const int32_t *__restrict__ knn_idx,
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
     {
         const int p = wave;
         const size_t gp = g0 + p;
-        const bool live = gp < total;                                   // wave-uniform
+        const bool live = gp < total && !(ABL & 4);                     // wave-uniform
         uint32_t bits = 0;
         int s_done = 0;
         // channels 2 lane, 2 lane + 1 sit in octet lane / 4 at half positions 2 (lane % 4), + 1
@@ -101,8 +111,9 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
             const float *trow = f_rows + gp * DCLR_F_STRIDE;             // template clouds come first
             const float tx = trow[64], ty = trow[65], tz = trow[66];
             const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
-            const int my_nb = lane < k ? knn_idx[gp * k + lane] : 0;
-            const float4 nbp = *reinterpret_cast<const float4 *>(f_rows + (src0 + my_nb) * DCLR_F_STRIDE + 64);
+            const int my_nb = (ABL & 1) ? (lane & 15) : (lane < k ? knn_idx[gp * k + lane] : 0);
+            const float4 nbp = (ABL & 1) ? make_float4(tx + lane, ty, tz, 0.f)
+                                         : *reinterpret_cast<const float4 *>(f_rows + (src0 + my_nb) * DCLR_F_STRIDE + 64);
             const float my_dx = nbp.x - tx, my_dy = nbp.y - ty, my_dz = nbp.z - tz;
             const float norm = sqrtf(my_dx * my_dx + my_dy * my_dy + my_dz * my_dz);
             bits = (uint32_t)__ballot(lane < k && (!(radius > 0.f) || norm < radius));
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
 #pragma unroll
             for (int s = 0; s < KMAX; ++s) {
                 const int nb = __builtin_amdgcn_readlane(my_nb, s < k ? s : 0);     // s >= k: a harmless repeat
-                psv[s] = *reinterpret_cast<const float2 *>(psrow + (size_t)nb * F16_C);
+                psv[s] = (ABL & 1) ? make_float2(0.01f * nb, 0.02f * lane) : *reinterpret_cast<const float2 *>(psrow + (size_t)nb * F16_C);
             }
             const float2 ptv = *reinterpret_cast<const float2 *>(pt + gp * F16_C + 2 * lane);
             const float2 bv = *reinterpret_cast<const float2 *>(b1 + 2 * lane);
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
             }
         }
         const float4 *wh = w2p + (size_t)(2 * wave) * F16_KG * 64 + lane;
-        flow16_panel<T, true>(acc, acc2, a_lane, wh, wh + (size_t)(F16_C / 16) * F16_KG * 64, F16_KG * 64);
+        flow16_panel<T, true, ABL>(acc, acc2, a_lane, wh, wh + (size_t)(F16_C / 16) * F16_KG * 64, F16_KG * 64);
         __syncthreads();                                   // every wave has consumed the layer-1 rows
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                 }
             }
             const float4 *wh = w3p + (size_t)tile0 * F16_KG * 64 + lane;
-            flow16_panel<T, false>(acc, acc2, a_lane, wh, wh + (size_t)(F16_OUT / 16) * F16_KG * 64, F16_KG * 64);
+            flow16_panel<T, false, ABL>(acc, acc2, a_lane, wh, wh + (size_t)(F16_OUT / 16) * F16_KG * 64, F16_KG * 64);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float mx = 0.f;                            // ReLU output floor
@@ -234,12 +245,12 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
     }
 }
 
-template <int T>
+template <int T, int ABL = 0>
 void flow16_launch(int pairs, int npoint, int k, float radius, const float *f_rows, const int32_t *knn_idx,
                    const float *pt, const float *ps, const float *w1a, const float *b1, const void *w2p,
                    const float *b2, const void *w3p, const float *b3, float *e_rows, hipStream_t stream) {
     const size_t total = (size_t)pairs * npoint;
-    hipLaunchKernelGGL((flow16_kernel<T>), dim3((unsigned)((total + F16_G - 1) / F16_G)), dim3(256), 0, stream, pairs,
+    hipLaunchKernelGGL((flow16_kernel<T, ABL>), dim3((unsigned)((total + F16_G - 1) / F16_G)), dim3(256), 0, stream, pairs,
                        npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, reinterpret_cast<const float4 *>(w2p), b2,
                        reinterpret_cast<const float4 *>(w3p), b3, e_rows);
 }
@@ -256,6 +267,13 @@ extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float
     DCLR_REQUIRE(((uintptr_t)w2p & 15) == 0 && ((uintptr_t)w3p & 15) == 0 && ((uintptr_t)pt & 7) == 0 &&
                  ((uintptr_t)ps & 7) == 0 && ((uintptr_t)b2 & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    static const int abl = getenv("DCLR_FLOW_ABL") ? atoi(getenv("DCLR_FLOW_ABL")) : 0;      // measurement switch (k = 20 only)
+    if (abl != 0 && (k + 3) / 4 == 5) {
+#define DCLR_FLOW16_ABL(A) case A: flow16_launch<5, A>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
+        switch (abl) { DCLR_FLOW16_ABL(1); DCLR_FLOW16_ABL(2); DCLR_FLOW16_ABL(3); DCLR_FLOW16_ABL(4); DCLR_FLOW16_ABL(6); default: break; }
+#undef DCLR_FLOW16_ABL
+        return dclr_launch_status();
+    }
 #define DCLR_FLOW16_CASE(T) case T: flow16_launch<T>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
     switch ((k + 3) / 4) {
         DCLR_FLOW16_CASE(1); DCLR_FLOW16_CASE(2); DCLR_FLOW16_CASE(3); DCLR_FLOW16_CASE(4);

@@ -329,7 +329,12 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     __shared__ unsigned long long wpk[2][16];              // MULTI: per-wave packed candidate, by round parity
     __shared__ uint32_t wru[2][16];                        // MULTI: per-wave runner-up (largest other running minimum)
     __shared__ float plist[4][4];                          // MULTI: the samples accepted for the next round
-    __shared__ uint4 gtab[2][64][2];                       // MODE 2: per-group candidate table, by round parity
+    __shared__ uint4 gtab[2][64][2];                       // MODE 2: per-group candidate table; MODE 4: per-wave chains, by round parity
+    __shared__ float4 alist[16];                           // MODE 4: the picks accepted in this round
+    __shared__ unsigned long long amask[16];               // MODE 4: ... and the groups each of them can change (bit = group)
+    __shared__ float gbox_lds[64][8];                      // MODE 4: every group's box, for the leader's pruning tests
+    __shared__ float gmax_lds[64];                         // MODE 4: ... and an upper bound of its largest running minimum
+    __shared__ int alist_n;
     __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
@@ -522,7 +527,254 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     unsigned long long acc_upd = 0, acc_bar = 0, acc_comb = 0, n_act = 0;
     unsigned long long dbg_box = 0, dbg_upd = 0, dbg_sel = 0, dbg_pub = 0, dbg_idle = 0, dbg_nact = 0;
 #endif
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 4) {
+
+        // ---- speculative chains: several samples per round, several of them from the SAME wave -----------------
+        // Every wave runs its own greedy chain of K picks ahead: s_0 = its point with the largest running minimum,
+        // s_1 = the same after s_0 has been applied to ITS points, ... (virtually: the running minima are not
+        // written). With td* the true state after the picks accepted so far, a wave's chain head c (value v) is
+        // still that wave's true arg-max iff no accepted pick of ANOTHER wave has reached it (sqdist(q, c) >= v for
+        // all of them): its own accepted picks are in the chain by construction and everything else in the wave
+        // only got smaller (ties: c had the smallest key among the wave's maxima). The leader merges the 16 chains:
+        // repeatedly the best head (value, then key) over all waves -- a head some foreign pick reached ("dirty"),
+        // or the last element of a chain already used up, only carries an UPPER bound of its wave's maximum, so the
+        // round ends when such a head comes out on top; a clean one is the next sample exactly, the chain moves on and
+        // every candidate of the other waves checks itself against the new pick. Then all waves apply the accepted
+        // picks to their points for real. Per-wave candidates behind a leader (MODE 1) stop whenever the next
+        // sample lies in the wave of the previous one (its runner-up); here that is just the next chain element.
+#ifndef FPS_CHAIN_K
+#define FPS_CHAIN_K 4
+#endif
+        constexpr int K = FPS_CHAIN_K;                                 // chain length: one candidate per leader lane
+        constexpr int JMAX = 12;                                       // picks per round (alist holds 16)
+        static_assert(NW * K <= 64 && K >= 2 && K <= 4, "one lane per candidate");
+        // group boxes and bounds for the leader (lane g < G of every wave owns group wave * G + g)
+        if (lane < G) {
+            float *gb = gbox_lds[wave * G + lane];
+            gb[0] = glo[0]; gb[1] = glo[1]; gb[2] = glo[2]; gb[3] = ghi[0]; gb[4] = ghi[1]; gb[5] = ghi[2];
+            gmax_lds[wave * G + lane] = gmaxv;              // +inf (non-empty group: forces the first update) or 0
+        }
+        if (t == 0) { alist[0] = make_float4(cx, cy, cz, 0.f); amask[0] = ~0ull; alist_n = 1; }
+        __syncthreads();
+        constexpr int NG4 = NW * G;
+        float lbx[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};     // leader: lane L = group L's box
+        if (wave == 0 && lane < NG4) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) lbx[a] = gbox_lds[lane][a];
+        }
+        int sr = 0;
+        for (int r = 1; r < m;) {
+#ifdef FPS_DEBUG
+            unsigned long long c0, c1, c2, c3, c4;
+            FPS_STAMP(c0);
+#endif
+            // ---- apply the picks accepted in the previous round (own and foreign alike); which groups a pick can
+            //      change was decided by the leader, 64 groups per instruction, instead of 16 waves x 4 lanes each ----
+            const int np = alist_n;
+            uint32_t touched = 0;
+#pragma unroll 1
+            for (int j = 0; j < np; ++j) {
+                const unsigned long long mk = amask[j];
+                const uint32_t act = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mk >> (wave * G))) & ((1u << G) - 1u);
+                if (act == 0) continue;                                   // wave-uniform
+                const float4 sp = alist[j];
+                const float sx = sp.x, sy = sp.y, sz = sp.z;
+                touched |= act;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (act & (1u << g)) {
+                        float best = -1.0f;
+                        int bjj = g * S;
+#pragma unroll
+                        for (int i = 0; i < S; ++i) {
+                            const int jj = g * S + i;
+                            const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), sx, sy, sz);
+                            float d2;
+                            asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                            vec_set<P>(td, jj, d2);
+                            const bool gt = d2 > best;
+                            bjj = gt ? jj : bjj;
+                            best = gt ? d2 : best;
+                        }
+                        gbest[g] = best; gjj[g] = bjj;
+                    }
+                }
+            }
+            if (touched != 0 && (sr & 3) == 1) {                          // tighten the pruning bounds now and then
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float gm = __uint_as_float(dclr_wave_max_u32(gbest[g] < 0.f ? 0u : __float_as_uint(gbest[g])));
+                    gmaxv = lane == g ? gm : gmaxv;
+                }
+                if (lane < G) gmax_lds[wave * G + lane] = gmaxv;          // read by the leader after the next barrier
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(c1);
+#endif
+            // ---- this wave's chain: K picks ahead, running minima untouched ------------------------------------
+            float tb[G];
+            int tj[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) { tb[g] = gbest[g]; tj[g] = gjj[g]; }
+            float chx[K], chy[K], chz[K];
+            uint32_t chv[K];
+            int chl[K], chj[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float lbest = tb[0];
+#pragma unroll
+                for (int g = 1; g < G; ++g) lbest = fmaxf(lbest, tb[g]);
+                const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
+                const float wmaxf = __uint_as_float(wmax);
+                int hits = 0, hjj = 0;
+#pragma unroll
+                for (int g = G - 1; g >= 0; --g) {
+                    const bool eq = tb[g] == wmaxf;
+                    hits += eq ? 1 : 0;
+                    hjj = eq ? tj[g] : hjj;
+                }
+                const uint64_t lanes_hit = __ballot(hits > 0);
+                int wl, wjj;
+                if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
+                    wl = __builtin_ctzll(lanes_hit);
+                    wjj = __builtin_amdgcn_readlane(hjj, wl);
+                } else {                                                  // exact tie: smallest tie key among the holders
+                    uint32_t key = 0xFFFFFFFFu;
+                    int kjj = 0;
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        uint32_t kg = 0xFFFFu;
+                        if (tb[g] == wmaxf) kg = skey[tj[g] * 64];
+                        const bool take = tb[g] == wmaxf && kg < key;
+                        key = take ? kg : key;
+                        kjj = take ? tj[g] : kjj;
+                    }
+                    const uint32_t wkey = dclr_wave_min_u32(key);
+                    wl = __builtin_ctzll(__ballot(key == wkey));
+                    wjj = __builtin_amdgcn_readlane(kjj, wl);
+                }
+                const float sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
+                const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
+                const float sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
+                chx[i] = sx; chy[i] = sy; chz[i] = sz; chv[i] = wmax; chl[i] = wl; chj[i] = wjj;
+                if (i + 1 < K) {
+                    // virtual application of s_i: the groups it can change get their maxima recomputed from the true
+                    // running minima and ALL chain picks so far (an earlier pick may have reached the group too)
+                    const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], sx, sy, sz);
+                    const uint32_t act = (uint32_t)__ballot(lbv < gmaxv);
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (act & (1u << g)) {                            // wave-uniform
+                            float best = -1.0f;
+                            int bjj = g * S;
+#pragma unroll
+                            for (int u = 0; u < S; ++u) {
+                                const int jj = g * S + u;
+                                float v = vec_get<P>(td, jj);
+#pragma unroll
+                                for (int c = 0; c <= i; ++c) {
+                                    const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj),
+                                                                chx[c], chy[c], chz[c]);
+                                    float d2;
+                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(v));
+                                    v = d2;
+                                }
+                                const bool gt = v > best;
+                                bjj = gt ? jj : bjj;
+                                best = gt ? v : best;
+                            }
+                            tb[g] = best; tj[g] = bjj;
+                        }
+                    }
+                }
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(c2);
+#endif
+            // publish: lane i < K writes chain element i (value, tie key, index, coordinates)
+            const int par = sr & 1;
+            {
+                uint32_t pv = 0, pkey = 0xFFFFu;
+                float qx = 0.f, qy = 0.f, qz = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    if (lane == i) {
+                        pv = chv[i]; qx = chx[i]; qy = chy[i]; qz = chz[i];
+                        pkey = sbuf[wave * 64 * P + chj[i] * 64 + chl[i]];
+                    }
+                }
+                if (lane < K) {
+                    gtab[par][wave * K + lane][0] = make_uint4(pv, pkey, fps_tk1024_inv(pkey), 0u);
+                    gtab[par][wave * K + lane][1] = make_uint4(__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz), 0u);
+                }
+            }
+            __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(c3);
+#endif
+            // ---- the leader merges the chains -----------------------------------------------------------------
+            if (wave == 0) {
+                const bool cand = lane < NW * K;
+                const uint4 e0 = gtab[par][cand ? lane : 0][0], e1 = gtab[par][cand ? lane : 0][1];
+                const float gbound = lane < NG4 ? gmax_lds[lane] : 0.f;   // lane L: bound of group L (valid: minima only shrink)
+                const int cw = cand ? lane / K : -1, ci = lane % K;
+                const float mx = __uint_as_float(e1.x), my = __uint_as_float(e1.y), mz = __uint_as_float(e1.z);
+                const uint32_t val = e0.x, tkey = e0.y;
+                bool head = cand && ci == 0, dirty = false;
+                int n = 0;
+#pragma unroll 1
+                for (int j = 0; j < JMAX; ++j) {
+                    if (r + n >= m) break;                                // uniform
+                    const uint32_t hv = head ? val : 0u;
+                    const uint32_t m_hi = dclr_wave_max_u32(hv);
+                    const uint64_t holders = __ballot(head && val == m_hi);
+                    int wid;
+                    if ((holders & (holders - 1)) == 0) wid = holders ? __builtin_ctzll(holders) : 0;
+                    else {
+                        const uint32_t kmin = dclr_wave_min_u32(head && val == m_hi ? tkey : 0xFFFFFFFFu);
+                        wid = __builtin_ctzll(__ballot(head && val == m_hi && tkey == kmin));
+                    }
+                    const bool d_w = __builtin_amdgcn_readlane((int)dirty, wid) != 0;
+                    if (d_w) break;                                       // only an upper bound of that wave's maximum
+                    if (m_hi == 0u && n > 0) break;                       // exhausted cloud: one pick per round
+                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mx), wid));
+                    const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my), wid));
+                    const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mz), wid));
+                    // the groups this pick can change: rounded lower bound of its distance to the group's box below the
+                    // group's largest running minimum (all 64 groups at once)
+                    const float lbv = fps_box_lower_bound(lbx[0], lbx[1], lbx[2], lbx[3], lbx[4], lbx[5], x, y, z);
+                    const unsigned long long reach = __ballot(lane < NG4 && lbv < gbound);
+                    if (lane == 0) {
+                        picked[r + n] = __builtin_amdgcn_readlane((int)e0.z, wid);
+                        alist[n] = make_float4(x, y, z, 0.f);
+                        amask[n] = reach;
+                    }
+                    n += 1;
+                    const int ww = wid / K, wi = wid % K;
+                    // candidates of the other waves the new pick reaches no longer stand for their wave's maximum
+                    const uint32_t dist = __float_as_uint(dclr_sqdist(mx, my, mz, x, y, z));
+                    dirty = dirty || (cw != ww && dist < val);
+                    // the chain of the pick's wave moves on; behind its last element only that element's value is known
+                    if (cw == ww) {
+                        if (wi + 1 < K) head = ci == wi + 1;
+                        else { head = ci == wi; dirty = dirty || ci == wi; }
+                    }
+                }
+                if (lane == 0) alist_n = n;
+            }
+            __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(c4);
+            if (lane == 0 && blockIdx.x == 0 && (wave == 0 || wave == 3)) {
+                unsigned long long *d = fps_dbg + (wave == 0 ? 0 : 8);
+                d[0] += c1 - c0; d[1] += c2 - c1; d[2] += c3 - c2; d[3] += c4 - c3; d[4] += 1; d[5] += alist_n;
+            }
+#endif
+            r += alist_n;
+            sr += 1;
+        }
+        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
+    } else if constexpr (MODE == 2) {
 
         // ---- several samples per barrier round, candidates per GROUP, one barrier per round --------------------
         // Every group (256 points at P = 16) keeps an exact table entry: its largest running minimum b_g, that
@@ -1611,7 +1863,7 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
     // A/B switches: DCLR_FPS_SINGLE = one sample per barrier round, DCLR_FPS_WAVECAND = several with per-wave candidates
-    static const int env_mode = getenv("DCLR_FPS_SINGLE") ? 0 : (getenv("DCLR_FPS_GROUPCAND16") ? 2 : 1);
+    static const int env_mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_GROUPCAND16") ? 2 : getenv("DCLR_FPS_WAVECAND") ? 1 : 4;
     const int mode = FORCE_MODE >= 0 ? FORCE_MODE : env_mode;
     if (mode == 3)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 3>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
@@ -1622,8 +1874,11 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     else if (mode == 1)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
-    else
+    else if (mode == 2)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 2>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+                           group_pts, group_box);
+    else
+        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 4>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
 }
 

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-LIB_PATH = os.path.join(_CSRC, 'libdeepclr_amd.so')
+LIB_PATH = os.environ.get('DCLR_LIB', os.path.join(_CSRC, 'libdeepclr_amd.so'))      # DCLR_LIB: A/B builds (scratch/)
 
 _i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 

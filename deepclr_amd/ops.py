@@ -105,8 +105,10 @@ def grouping_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tenso
 
 
 def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor] = None,
-        batch_y: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index]."""
+        batch_y: Optional[torch.Tensor] = None, batch_size: Optional[int] = None) -> torch.Tensor:
+    """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index].
+    The batch count has to be known on the host (it sizes the launch): one device-to-host read of the two batch
+    vectors' last entries, none when the caller passes ``batch_size`` (torch_cluster >= 1.6 takes the same argument)."""
     x, y = lib.dev_f32(x, 'x'), lib.dev_f32(y, 'y')
     if x.dim() != 2 or x.shape[1] != 3 or y.shape[1] != 3:
         raise RuntimeError("knn: only 3-d points are supported")
@@ -114,9 +116,13 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor
     if batch_x is not None or batch_y is not None:
         if batch_x is None or batch_y is None:
             raise RuntimeError("knn: give both batch vectors or neither")
-        b = int(batch_x[-1].item()) + 1
-        if int(batch_y[-1].item()) + 1 != b:
-            raise RuntimeError("knn: batch_x and batch_y disagree on the batch size")
+        if batch_size is not None:
+            b = int(batch_size)
+        else:
+            last = torch.stack((batch_x[-1], batch_y[-1])).cpu()         # ONE host synchronisation
+            b = int(last[0]) + 1
+            if int(last[1]) + 1 != b:
+                raise RuntimeError("knn: batch_x and batch_y disagree on the batch size")
     nx, ny = x.shape[0] // b, y.shape[0] // b
     if nx * b != x.shape[0] or ny * b != y.shape[0]:
         raise RuntimeError("knn: only equally sized batch items are supported")

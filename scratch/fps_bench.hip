@@ -31,6 +31,11 @@ int main(int argc, char **argv) {
         printf("rc=%d  %.1f us | active groups/round %.2f of 64 | cycles/round wave0/cloud0: update+publish %.0f barrier-wait %.0f combine %.0f total %.0f\n",
                rc, ms * 1e3, dbg[0] / (rounds * b), dbg[1] / rounds, dbg[2] / rounds, dbg[3] / rounds, dbg[4] / rounds);
         printf("   super-rounds: %llu for %d samples | wave 3 per super-round (cycles): updates %.0f select %.0f publish+barrier %.0f combine %.0f | touched in %llu\n", dbg[11], m - 1, (double)dbg[12] / dbg[11], (double)dbg[13] / dbg[11], (double)dbg[14] / dbg[11], (double)dbg[15] / dbg[11], dbg[10]);
+        for (int w = 0; w < 2; ++w) {
+            const unsigned long long *d = dbg + 8 * w;
+            if (d[4]) printf("   chains mode, wave %d: rounds %llu picks %llu | per round (cycles): apply %.0f chain %.0f publish+barrier %.0f merge(+barrier) %.0f\n",
+                             w ? 3 : 0, d[4], d[5], (double)d[0] / d[4], (double)d[1] / d[4], (double)d[2] / d[4], (double)d[3] / d[4]);
+        }
         const double na = dbg[10] ? (double)dbg[10] : 1.0, ni = rounds - dbg[10] > 0 ? rounds - dbg[10] : 1.0;
         printf("   wave0/cloud0: active in %.0f of %.0f rounds; per ACTIVE round: box %.0f update %.0f select %.0f publish %.0f | per IDLE round: pre-barrier %.0f\n",
                (double)dbg[10], rounds, dbg[5] / na, dbg[6] / na, dbg[7] / na, dbg[8] / na, dbg[9] / ni);
