@@ -460,7 +460,7 @@ def run(args):
     fence()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
-    alone = None
+    alone, fps_rounds = None, None
     if timer is not None and rank == 0:
         # second, untimed pass: the same launches one after another on one stream, so that each kernel's
         # duration is its own (in the timed region they share the CUs with the sampler running ahead)
@@ -487,6 +487,12 @@ def run(args):
         torch.cuda.synchronize()
         ops.TIMER = None
         alone = solo.summary()
+        fps_rounds = None
+        if not args.sequence:
+            with torch.no_grad():
+                sample = model.sample(xs)                      # (idx, group_pts, group_box): box[:, 0, 6] = barrier rounds
+            if sample[2] is not None:
+                fps_rounds = float(sample[2][:, 0, 6].mean())
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -519,7 +525,9 @@ def run(args):
                     extra = dict(extra, sample_rounds_per_s_per_cloud=extra['samples_per_cloud'] / sec,
                                  sample_rounds_per_s=extra['samples_per_cloud'] * extra['clouds_per_launch'] / sec,
                                  dist_evals_per_s=extra['dist_evals'] / sec,
-                                 us_per_sample=1e6 * sec / extra['samples_per_cloud'])
+                                 us_per_sample=1e6 * sec / extra['samples_per_cloud'],
+                                 barrier_rounds_per_cloud=fps_rounds,
+                                 samples_per_round=None if not fps_rounds else extra['samples_per_cloud'] / fps_rounds)
                 else:
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
                 solo_us = alone[name]['avg_us'] if alone and name in alone else None

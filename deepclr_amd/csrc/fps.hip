@@ -314,7 +314,7 @@ struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
 };
 
 // WGS threads, P points per thread (WGS * P = padded cloud size, a power of two), G groups per wave.
-template <int WGS, int P, int G, int MODE>      // MODE 0: one sample per round; 1: several, per-wave candidates; 2: several, per-group
+template <int WGS, int P, int G, int MODE>      // MODE 0: one sample per barrier round; 1: several (per-wave candidates)
 __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int m,
                                                          const float *__restrict__ pts,
                                                          float *__restrict__ temp,
@@ -329,12 +329,6 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     __shared__ unsigned long long wpk[2][16];              // MULTI: per-wave packed candidate, by round parity
     __shared__ uint32_t wru[2][16];                        // MULTI: per-wave runner-up (largest other running minimum)
     __shared__ float plist[4][4];                          // MULTI: the samples accepted for the next round
-    __shared__ uint4 gtab[2][64][2];                       // MODE 2: per-group candidate table; MODE 4: per-wave chains, by round parity
-    __shared__ float4 alist[16];                           // MODE 4: the picks accepted in this round
-    __shared__ unsigned long long amask[16];               // MODE 4: ... and the groups each of them can change (bit = group)
-    __shared__ float gbox_lds[64][8];                      // MODE 4: every group's box, for the leader's pruning tests
-    __shared__ float gmax_lds[64];                         // MODE 4: ... and an upper bound of its largest running minimum
-    __shared__ int alist_n;
     __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
@@ -511,7 +505,6 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
     }
     __syncthreads();                                       // `cellof` is dead: `picked` (same storage) may be written
-    if constexpr (MODE == 3) return;                       // partition only: fps_quad_kernel samples from group_pts / group_box
 
     float cx = pts[0], cy = pts[1], cz = pts[2];
     if (t == 0) picked[0] = 0;
@@ -527,417 +520,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     unsigned long long acc_upd = 0, acc_bar = 0, acc_comb = 0, n_act = 0;
     unsigned long long dbg_box = 0, dbg_upd = 0, dbg_sel = 0, dbg_pub = 0, dbg_idle = 0, dbg_nact = 0;
 #endif
-    if constexpr (MODE == 4) {
-
-        // ---- speculative chains: several samples per round, several of them from the SAME wave -----------------
-        // Every wave runs its own greedy chain of K picks ahead: s_0 = its point with the largest running minimum,
-        // s_1 = the same after s_0 has been applied to ITS points, ... (virtually: the running minima are not
-        // written). With td* the true state after the picks accepted so far, a wave's chain head c (value v) is
-        // still that wave's true arg-max iff no accepted pick of ANOTHER wave has reached it (sqdist(q, c) >= v for
-        // all of them): its own accepted picks are in the chain by construction and everything else in the wave
-        // only got smaller (ties: c had the smallest key among the wave's maxima). The leader merges the 16 chains:
-        // repeatedly the best head (value, then key) over all waves -- a head some foreign pick reached ("dirty"),
-        // or the last element of a chain already used up, only carries an UPPER bound of its wave's maximum, so the
-        // round ends when such a head comes out on top; a clean one is the next sample exactly, the chain moves on and
-        // every candidate of the other waves checks itself against the new pick. Then all waves apply the accepted
-        // picks to their points for real. Per-wave candidates behind a leader (MODE 1) stop whenever the next
-        // sample lies in the wave of the previous one (its runner-up); here that is just the next chain element.
-#ifndef FPS_CHAIN_K
-#define FPS_CHAIN_K 4
-#endif
-        constexpr int K = FPS_CHAIN_K;                                 // chain length: one candidate per leader lane
-        constexpr int JMAX = 12;                                       // picks per round (alist holds 16)
-        static_assert(NW * K <= 64 && K >= 2 && K <= 4, "one lane per candidate");
-        // group boxes and bounds for the leader (lane g < G of every wave owns group wave * G + g)
-        if (lane < G) {
-            float *gb = gbox_lds[wave * G + lane];
-            gb[0] = glo[0]; gb[1] = glo[1]; gb[2] = glo[2]; gb[3] = ghi[0]; gb[4] = ghi[1]; gb[5] = ghi[2];
-            gmax_lds[wave * G + lane] = gmaxv;              // +inf (non-empty group: forces the first update) or 0
-        }
-        if (t == 0) { alist[0] = make_float4(cx, cy, cz, 0.f); amask[0] = ~0ull; alist_n = 1; }
-        __syncthreads();
-        constexpr int NG4 = NW * G;
-        float lbx[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};     // leader: lane L = group L's box
-        if (wave == 0 && lane < NG4) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) lbx[a] = gbox_lds[lane][a];
-        }
-        int sr = 0;
-        for (int r = 1; r < m;) {
-#ifdef FPS_DEBUG
-            unsigned long long c0, c1, c2, c3, c4;
-            FPS_STAMP(c0);
-#endif
-            // ---- apply the picks accepted in the previous round (own and foreign alike); which groups a pick can
-            //      change was decided by the leader, 64 groups per instruction, instead of 16 waves x 4 lanes each ----
-            const int np = alist_n;
-            uint32_t touched = 0;
-#pragma unroll 1
-            for (int j = 0; j < np; ++j) {
-                const unsigned long long mk = amask[j];
-                const uint32_t act = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mk >> (wave * G))) & ((1u << G) - 1u);
-                if (act == 0) continue;                                   // wave-uniform
-                const float4 sp = alist[j];
-                const float sx = sp.x, sy = sp.y, sz = sp.z;
-                touched |= act;
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (act & (1u << g)) {
-                        float best = -1.0f;
-                        int bjj = g * S;
-#pragma unroll
-                        for (int i = 0; i < S; ++i) {
-                            const int jj = g * S + i;
-                            const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), sx, sy, sz);
-                            float d2;
-                            asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
-                            vec_set<P>(td, jj, d2);
-                            const bool gt = d2 > best;
-                            bjj = gt ? jj : bjj;
-                            best = gt ? d2 : best;
-                        }
-                        gbest[g] = best; gjj[g] = bjj;
-                    }
-                }
-            }
-            if (touched != 0 && (sr & 3) == 1) {                          // tighten the pruning bounds now and then
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const float gm = __uint_as_float(dclr_wave_max_u32(gbest[g] < 0.f ? 0u : __float_as_uint(gbest[g])));
-                    gmaxv = lane == g ? gm : gmaxv;
-                }
-                if (lane < G) gmax_lds[wave * G + lane] = gmaxv;          // read by the leader after the next barrier
-            }
-#ifdef FPS_DEBUG
-            FPS_STAMP(c1);
-#endif
-            // ---- this wave's chain: K picks ahead, running minima untouched ------------------------------------
-            float tb[G];
-            int tj[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) { tb[g] = gbest[g]; tj[g] = gjj[g]; }
-            float chx[K], chy[K], chz[K];
-            uint32_t chv[K];
-            int chl[K], chj[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                float lbest = tb[0];
-#pragma unroll
-                for (int g = 1; g < G; ++g) lbest = fmaxf(lbest, tb[g]);
-                const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
-                const float wmaxf = __uint_as_float(wmax);
-                int hits = 0, hjj = 0;
-#pragma unroll
-                for (int g = G - 1; g >= 0; --g) {
-                    const bool eq = tb[g] == wmaxf;
-                    hits += eq ? 1 : 0;
-                    hjj = eq ? tj[g] : hjj;
-                }
-                const uint64_t lanes_hit = __ballot(hits > 0);
-                int wl, wjj;
-                if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
-                    wl = __builtin_ctzll(lanes_hit);
-                    wjj = __builtin_amdgcn_readlane(hjj, wl);
-                } else {                                                  // exact tie: smallest tie key among the holders
-                    uint32_t key = 0xFFFFFFFFu;
-                    int kjj = 0;
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        uint32_t kg = 0xFFFFu;
-                        if (tb[g] == wmaxf) kg = skey[tj[g] * 64];
-                        const bool take = tb[g] == wmaxf && kg < key;
-                        key = take ? kg : key;
-                        kjj = take ? tj[g] : kjj;
-                    }
-                    const uint32_t wkey = dclr_wave_min_u32(key);
-                    wl = __builtin_ctzll(__ballot(key == wkey));
-                    wjj = __builtin_amdgcn_readlane(kjj, wl);
-                }
-                const float sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
-                const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
-                const float sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
-                chx[i] = sx; chy[i] = sy; chz[i] = sz; chv[i] = wmax; chl[i] = wl; chj[i] = wjj;
-                if (i + 1 < K) {
-                    // virtual application of s_i: the groups it can change get their maxima recomputed from the true
-                    // running minima and ALL chain picks so far (an earlier pick may have reached the group too)
-                    const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], sx, sy, sz);
-                    const uint32_t act = (uint32_t)__ballot(lbv < gmaxv);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if (act & (1u << g)) {                            // wave-uniform
-                            float best = -1.0f;
-                            int bjj = g * S;
-#pragma unroll
-                            for (int u = 0; u < S; ++u) {
-                                const int jj = g * S + u;
-                                float v = vec_get<P>(td, jj);
-#pragma unroll
-                                for (int c = 0; c <= i; ++c) {
-                                    const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj),
-                                                                chx[c], chy[c], chz[c]);
-                                    float d2;
-                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(v));
-                                    v = d2;
-                                }
-                                const bool gt = v > best;
-                                bjj = gt ? jj : bjj;
-                                best = gt ? v : best;
-                            }
-                            tb[g] = best; tj[g] = bjj;
-                        }
-                    }
-                }
-            }
-#ifdef FPS_DEBUG
-            FPS_STAMP(c2);
-#endif
-            // publish: lane i < K writes chain element i (value, tie key, index, coordinates)
-            const int par = sr & 1;
-            {
-                uint32_t pv = 0, pkey = 0xFFFFu;
-                float qx = 0.f, qy = 0.f, qz = 0.f;
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    if (lane == i) {
-                        pv = chv[i]; qx = chx[i]; qy = chy[i]; qz = chz[i];
-                        pkey = sbuf[wave * 64 * P + chj[i] * 64 + chl[i]];
-                    }
-                }
-                if (lane < K) {
-                    gtab[par][wave * K + lane][0] = make_uint4(pv, pkey, fps_tk1024_inv(pkey), 0u);
-                    gtab[par][wave * K + lane][1] = make_uint4(__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz), 0u);
-                }
-            }
-            __syncthreads();
-#ifdef FPS_DEBUG
-            FPS_STAMP(c3);
-#endif
-            // ---- the leader merges the chains -----------------------------------------------------------------
-            if (wave == 0) {
-                const bool cand = lane < NW * K;
-                const uint4 e0 = gtab[par][cand ? lane : 0][0], e1 = gtab[par][cand ? lane : 0][1];
-                const float gbound = lane < NG4 ? gmax_lds[lane] : 0.f;   // lane L: bound of group L (valid: minima only shrink)
-                const int cw = cand ? lane / K : -1, ci = lane % K;
-                const float mx = __uint_as_float(e1.x), my = __uint_as_float(e1.y), mz = __uint_as_float(e1.z);
-                const uint32_t val = e0.x, tkey = e0.y;
-                bool head = cand && ci == 0, dirty = false;
-                int n = 0;
-#pragma unroll 1
-                for (int j = 0; j < JMAX; ++j) {
-                    if (r + n >= m) break;                                // uniform
-                    const uint32_t hv = head ? val : 0u;
-                    const uint32_t m_hi = dclr_wave_max_u32(hv);
-                    const uint64_t holders = __ballot(head && val == m_hi);
-                    int wid;
-                    if ((holders & (holders - 1)) == 0) wid = holders ? __builtin_ctzll(holders) : 0;
-                    else {
-                        const uint32_t kmin = dclr_wave_min_u32(head && val == m_hi ? tkey : 0xFFFFFFFFu);
-                        wid = __builtin_ctzll(__ballot(head && val == m_hi && tkey == kmin));
-                    }
-                    const bool d_w = __builtin_amdgcn_readlane((int)dirty, wid) != 0;
-                    if (d_w) break;                                       // only an upper bound of that wave's maximum
-                    if (m_hi == 0u && n > 0) break;                       // exhausted cloud: one pick per round
-                    const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mx), wid));
-                    const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my), wid));
-                    const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mz), wid));
-                    // the groups this pick can change: rounded lower bound of its distance to the group's box below the
-                    // group's largest running minimum (all 64 groups at once)
-                    const float lbv = fps_box_lower_bound(lbx[0], lbx[1], lbx[2], lbx[3], lbx[4], lbx[5], x, y, z);
-                    const unsigned long long reach = __ballot(lane < NG4 && lbv < gbound);
-                    if (lane == 0) {
-                        picked[r + n] = __builtin_amdgcn_readlane((int)e0.z, wid);
-                        alist[n] = make_float4(x, y, z, 0.f);
-                        amask[n] = reach;
-                    }
-                    n += 1;
-                    const int ww = wid / K, wi = wid % K;
-                    // candidates of the other waves the new pick reaches no longer stand for their wave's maximum
-                    const uint32_t dist = __float_as_uint(dclr_sqdist(mx, my, mz, x, y, z));
-                    dirty = dirty || (cw != ww && dist < val);
-                    // the chain of the pick's wave moves on; behind its last element only that element's value is known
-                    if (cw == ww) {
-                        if (wi + 1 < K) head = ci == wi + 1;
-                        else { head = ci == wi; dirty = dirty || ci == wi; }
-                    }
-                }
-                if (lane == 0) alist_n = n;
-            }
-            __syncthreads();
-#ifdef FPS_DEBUG
-            FPS_STAMP(c4);
-            if (lane == 0 && blockIdx.x == 0 && (wave == 0 || wave == 3)) {
-                unsigned long long *d = fps_dbg + (wave == 0 ? 0 : 8);
-                d[0] += c1 - c0; d[1] += c2 - c1; d[2] += c3 - c2; d[3] += c4 - c3; d[4] += 1; d[5] += alist_n;
-            }
-#endif
-            r += alist_n;
-            sr += 1;
-        }
-        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
-    } else if constexpr (MODE == 2) {
-
-        // ---- several samples per barrier round, candidates per GROUP, one barrier per round --------------------
-        // Every group (256 points at P = 16) keeps an exact table entry: its largest running minimum b_g, that
-        // point's tie key, index and coordinates, and the runner-up u_g (largest running minimum among the group's
-        // other points). A round: (C) every wave applies the samples accepted in the previous round to the groups
-        // they can change (box test against the exact b_g) and recomputes the entries of those groups; it publishes
-        // its G entries; barrier; (A) every wave reads all entries, one per lane; (B) every wave derives, redundantly
-        // but identically, the next samples: p1 = best entry overall is sample r. The best remaining entry c (value v)
-        // is sample r + 1 as well if sqdist(c, p1) >= v (p1 leaves it untouched) and u_{g(p1)} < v (nothing else in
-        // p1's group can reach it; running minima only decrease): all other points are already ordered behind c by
-        // their groups' arg-max (ties by key). The same test against every sample accepted so far admits c as sample
-        // r + j. Untouched groups cost nothing, there is no leader wave and no second barrier; compared with per-wave
-        // candidates (MODE 1) the runner-up of 256 points instead of 1024 stands in the way less often.
-        constexpr int J = 4, NG = NW * G;
-        static_assert(NG <= 64, "one table entry per lane");
-        uint32_t o_val = __float_as_uint(gmaxv), o_tk = 0xFFFFu, o_ru = 0u;   // lane g < G: entry of this wave's group g
-        int32_t o_k = 0;                                                    // (+inf forces the first update of a non-empty group)
-        float o_x = 0.f, o_y = 0.f, o_z = 0.f;
-        float pcx[J] = {cx}, pcy[J] = {cy}, pcz[J] = {cz};
-        int np = 1, par = 0, sr = 0;
-        for (int r = 1; r < m;) {
-            uint32_t touched = 0;
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                if (j >= np) break;                                       // wave-uniform
-                const float sx = pcx[j], sy = pcy[j], sz = pcz[j];
-                const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], sx, sy, sz);
-                const uint32_t act = (uint32_t)__ballot(lane < G && lbv < __uint_as_float(o_val));
-                if (act == 0) continue;                                   // wave-uniform
-                touched |= act;
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    if (act & (1u << g)) {
-                        float best = -1.0f;
-                        int bjj = g * S;
-                        if constexpr (S % 2 == 0) {
-                            typedef float f2 __attribute__((ext_vector_type(2)));
-                            const f2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
-#pragma unroll
-                            for (int i = 0; i < S; i += 2) {
-                                const int jj = g * S + i;
-                                const f2 ax = {vec_get<P>(px, jj), vec_get<P>(px, jj + 1)};
-                                const f2 ay = {vec_get<P>(py, jj), vec_get<P>(py, jj + 1)};
-                                const f2 az = {vec_get<P>(pz, jj), vec_get<P>(pz, jj + 1)};
-                                const f2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
-                                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                                const f2 d = (xx + yy) + zz;
-#pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    float d2;
-                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d[h]), "v"(vec_get<P>(td, jj + h)));
-                                    vec_set<P>(td, jj + h, d2);
-                                    const bool gt = d2 > best;
-                                    bjj = gt ? jj + h : bjj;
-                                    best = gt ? d2 : best;
-                                }
-                            }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < S; ++i) {
-                                const int jj = g * S + i;
-                                const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), sx, sy, sz);
-                                float d2;
-                                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
-                                vec_set<P>(td, jj, d2);
-                                const bool gt = d2 > best;
-                                bjj = gt ? jj : bjj;
-                                best = gt ? d2 : best;
-                            }
-                        }
-                        gbest[g] = best; gjj[g] = bjj;
-                    }
-                }
-            }
-            // new table entries for the groups whose running minima may have changed
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                if (touched & (1u << g)) {                                // wave-uniform
-                    const bool real = gbest[g] >= 0.f;                    // this lane owns a real point of the group
-                    const uint32_t bits = real ? __float_as_uint(gbest[g]) : 0u;
-                    const uint32_t wmax = dclr_wave_max_u32(bits);
-                    const uint64_t hit = __ballot(real && bits == wmax);
-                    int wl, wjj;
-                    uint32_t wkey;
-                    if ((hit & (hit - 1)) == 0) {                         // one lane holds the maximum (the usual case)
-                        wl = __builtin_ctzll(hit);
-                        wjj = __builtin_amdgcn_readlane(gjj[g], wl);
-                        wkey = sbuf[wave * 64 * P + wjj * 64 + wl];
-                    } else {                                              // exact tie: smallest tie key among the holders
-                        uint32_t key = 0xFFFFFFFFu;
-                        if (real && bits == wmax) key = skey[gjj[g] * 64];
-                        wkey = dclr_wave_min_u32(key);
-                        wl = __builtin_ctzll(__ballot(key == wkey));
-                        wjj = __builtin_amdgcn_readlane(gjj[g], wl);
-                    }
-                    // runner-up: every other lane's best, and in the winner's lane the other slots of this group
-                    float other = -1.0f;
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const int jj = g * S + i;
-                        const float v = vec_get<P>(td, jj);
-                        other = jj != wjj ? fmaxf(other, v) : other;
-                    }
-                    const float alt = lane == wl ? other : gbest[g];
-                    const uint32_t ru = dclr_wave_max_u32(alt < 0.f ? 0u : __float_as_uint(alt));
-                    const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(px, wjj)), wl));
-                    const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(py, wjj)), wl));
-                    const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(vec_get<P>(pz, wjj)), wl));
-                    if (lane == g) {
-                        o_val = wmax; o_tk = wkey; o_ru = ru; o_k = (int32_t)fps_tk1024_inv(wkey);
-                        o_x = wx; o_y = wy; o_z = wz;
-                    }
-                }
-            }
-            if (lane < G) {
-                gtab[par][wave * G + lane][0] = make_uint4(o_val, o_tk, o_ru, (uint32_t)o_k);
-                gtab[par][wave * G + lane][1] = make_uint4(__float_as_uint(o_x), __float_as_uint(o_y), __float_as_uint(o_z), 0u);
-            }
-            __syncthreads();
-            const int le = lane < NG ? lane : 0;
-            const uint4 e0 = gtab[par][le][0], e1 = gtab[par][le][1];
-            uint32_t v = lane < NG ? e0.x : 0u, tk = lane < NG ? e0.y : 0xFFFFFFFFu;
-            uint32_t ru_acc[J];
-            float qx[J], qy[J], qz[J];
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                if (r + j >= m) break;                                    // uniform
-                const uint32_t m_hi = dclr_wave_max_u32(v);
-                const uint64_t holders = __ballot(v == m_hi);
-                int wid;
-                if ((holders & (holders - 1)) == 0) wid = __builtin_ctzll(holders);
-                else {
-                    const uint32_t kmin = dclr_wave_min_u32(v == m_hi ? tk : 0xFFFFFFFFu);
-                    wid = __builtin_ctzll(__ballot(v == m_hi && tk == kmin));
-                }
-                const float x = __uint_as_float(__builtin_amdgcn_readlane(e1.x, wid));
-                const float y = __uint_as_float(__builtin_amdgcn_readlane(e1.y, wid));
-                const float z = __uint_as_float(__builtin_amdgcn_readlane(e1.z, wid));
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < j; ++i) {
-                    const uint32_t dist = __float_as_uint(dclr_sqdist(x, y, z, qx[i], qy[i], qz[i]));
-                    ok = ok && m_hi > ru_acc[i] && dist >= m_hi;
-                }
-                if (!ok) break;                                           // uniform (never for j == 0)
-                qx[j] = x; qy[j] = y; qz[j] = z;
-                ru_acc[j] = (uint32_t)__builtin_amdgcn_readlane((int)e0.z, wid);
-                if (t == 0) picked[r + j] = __builtin_amdgcn_readlane((int)e0.w, wid);
-                cnt = j + 1;
-                const bool mine = lane == wid;
-                v = mine ? 0u : v;
-                tk = mine ? 0xFFFFFFFFu : tk;
-            }
-            np = cnt;
-#pragma unroll
-            for (int j = 0; j < J; ++j) { pcx[j] = qx[j]; pcy[j] = qy[j]; pcz[j] = qz[j]; }
-            r += cnt;
-            par ^= 1;
-            sr += 1;
-        }
-        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
-    } else if constexpr (MODE == 1) {
+    if constexpr (MODE == 1) {
         // ---- several samples per barrier round -----------------------------------------------------------
         // Sample r+1 is the point with the largest running minimum AFTER sample r has been applied. Let every
         // wave w publish its best point c_w (value b_w, tie key) and its runner-up value u_w = the largest
@@ -1152,6 +735,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
             mu += q1 - q0; ms += q2 - q1; mb += q3 - q2; mc += q4 - q3; mt += touched != 0 ? 1 : 0;
 #endif
         }
+        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
 #ifdef FPS_DEBUG
         if (lane == 0 && blockIdx.x == 0) { fps_dbg[11] = (unsigned long long)sr; if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = ms; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; } }
 #endif
@@ -1331,240 +915,6 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         for (int jj = 0; jj < P; ++jj)
             if (skey[jj * 64] != 0xFFFFu) temp[fps_tk1024_inv(skey[jj * 64])] = vec_get<P>(td, jj);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Kernel A'': the sampling rounds on FOUR waves (one per SIMD), fed by the spatial partition kernel A' leaves in
-// group_pts / group_box when it is launched in partition-only mode. Clouds of 1025..16384 points.
-//   * a wave owns G groups of S register slots (G * S = P points per lane; 16 groups x 4 slots at 16384 points: the same
-//     64 groups of 256 points kernel A' forms, in the same order);
-//   * every group keeps an exact table entry -- its largest running minimum b_g, that point's tie key, index and
-//     coordinates, and the runner-up u_g (largest running minimum among the group's other points);
-//   * a round: (C) every wave applies the samples accepted in the previous round to the groups they can change (box
-//     test against the exact b_g) and recomputes the entries of those groups; it publishes its G entries; ONE barrier;
-//     (A) every wave reads all entries, one per lane; (B) every wave derives, redundantly but identically, the next
-//     samples: p1 = best entry overall is sample r; the best remaining entry c (value v) is sample r + 1 as well if
-//     sqdist(c, p1) >= v (p1 leaves it untouched) and u_{g(p1)} < v (nothing else in p1's group can reach it; running
-//     minima only decrease): every other point is already ordered behind c by its group's arg-max (ties by key). The
-//     same test against every sample accepted so far admits c as sample r + j.
-// With one wave per SIMD the redundant step (B) costs no issue slots of another wave (on 16 waves it did: 1061 us
-// against 902 us for per-wave candidates behind a leader wave and a second barrier), untouched groups cost nothing,
-// and a workgroup is 256 threads and 8 KB of LDS instead of 1024 threads and 82 KB: other kernels' workgroups fit
-// beside it on the CU.
-// ------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ float fps_sel(const float *v, int s) {        // v[s] for s < N by selects (per-lane index)
-    float r = v[0];
-    asm("" : "+v"(r));        // opaque: keeps the optimiser from folding the selects into ONE load at a selected address,
-#pragma unroll                // which turns the register array into scratch memory
-    for (int i = 1; i < N; ++i) {
-        float a = v[i];
-        asm("" : "+v"(a));
-        r = s == i ? a : r;
-    }
-    return r;
-}
-
-template <int P, int G>
-__global__ __launch_bounds__(256, 1) void fps_quad_kernel(int n, int pstride, int m, const float *__restrict__ pts,
-                                                          int32_t *__restrict__ idx,
-                                                          const float4 *__restrict__ group_pts,
-                                                          float *__restrict__ group_box) {
-    constexpr int NW = 4, S = P / G, NG = NW * G, GS = 64 * S, J = 4;
-    static_assert(P % G == 0 && G <= 16 && G % 4 == 0 && S <= 4 && NG <= 64, "layout");
-    __shared__ uint4 gtab[2][64][2];
-    extern __shared__ int32_t picked[];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    pts += (size_t)blockIdx.x * n * pstride;
-    idx += (size_t)blockIdx.x * m;
-    group_pts += (size_t)blockIdx.x * NG * GS;
-    group_box += (size_t)blockIdx.x * NG * 8;
-
-    float px[P], py[P], pz[P], td[P];
-    uint32_t kk[(P + 1) / 2];                               // original index of the slot's point, two u16 per register
-                                                            // (n <= 16384; 0xFFFF = padding)
-    uint32_t nonempty = 0;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < S; ++i) {
-            const float4 q = group_pts[(size_t)(wave * G + g) * GS + i * 64 + lane];
-            const uint32_t k = __float_as_uint(q.w);
-            const bool ok = k != 0xFFFFFFFFu;
-            px[g * S + i] = q.x; py[g * S + i] = q.y; pz[g * S + i] = q.z;
-            td[g * S + i] = ok ? 1e10f : -2.0f;             // -2: padding can never beat best = -1
-            const int jj = g * S + i;
-            kk[jj / 2] = (jj & 1) ? (kk[jj / 2] | ((k & 0xFFFFu) << 16)) : (k & 0xFFFFu);
-            any = any || ok;
-        }
-        nonempty |= __ballot(any) != 0 ? 1u << g : 0u;
-    }
-    // lane g < G: box and table entry of this wave's group g
-    float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    if (lane < G) {
-        const float *gb = group_box + (size_t)(wave * G + lane) * 8;
-        glo[0] = gb[0]; glo[1] = gb[1]; glo[2] = gb[2]; ghi[0] = gb[3]; ghi[1] = gb[4]; ghi[2] = gb[5];
-    }
-    uint32_t o_val = (lane < G && ((nonempty >> lane) & 1u)) ? 0x7F800000u : 0u;   // +inf forces the first update
-    uint32_t o_tk = 0xFFFFu, o_ru = 0u, o_k = 0u;
-    float o_x = 0.f, o_y = 0.f, o_z = 0.f;
-
-    float pcx[J] = {pts[0], 0.f, 0.f, 0.f}, pcy[J] = {pts[1], 0.f, 0.f, 0.f}, pcz[J] = {pts[2], 0.f, 0.f, 0.f};
-    if (t == 0) picked[0] = 0;
-    int np = 1, par = 0, sr = 0;
-    for (int r = 1; r < m;) {
-        uint32_t touched = 0;
-#pragma unroll 1
-        for (int j = 0; j < np; ++j) {
-            const float sx = j == 0 ? pcx[0] : j == 1 ? pcx[1] : j == 2 ? pcx[2] : pcx[3];
-            const float sy = j == 0 ? pcy[0] : j == 1 ? pcy[1] : j == 2 ? pcy[2] : pcy[3];
-            const float sz = j == 0 ? pcz[0] : j == 1 ? pcz[1] : j == 2 ? pcz[2] : pcz[3];
-            const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], sx, sy, sz);
-            const uint32_t act = (uint32_t)__ballot(lane < G && lbv < __uint_as_float(o_val));
-            if (act == 0) continue;                                       // wave-uniform
-            touched |= act;
-#pragma unroll
-            for (int g4 = 0; g4 < G; g4 += 4) {
-                if (((act >> g4) & 15u) == 0) continue;                   // wave-uniform
-#pragma unroll
-                for (int gu = 0; gu < 4; ++gu) {
-                    const int g = g4 + gu;
-                    if (act & (1u << g)) {
-                        // the same IEEE operations in the same order as dclr_sqdist, two slots per instruction where S is even
-                        if constexpr (S % 2 == 0) {
-                            typedef float f2 __attribute__((ext_vector_type(2)));
-                            const f2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
-#pragma unroll
-                            for (int i = 0; i < S; i += 2) {
-                                const int jj = g * S + i;
-                                const f2 ax = {px[jj], px[jj + 1]}, ay = {py[jj], py[jj + 1]}, az = {pz[jj], pz[jj + 1]};
-                                const f2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
-                                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                                const f2 d = (xx + yy) + zz;
-#pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    float d2;               // plain v_min_f32: no canonicalising v_max in front of it
-                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d[h]), "v"(td[jj + h]));
-                                    td[jj + h] = d2;
-                                }
-                            }
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < S; ++i) {
-                                const int jj = g * S + i;
-                                const float d = dclr_sqdist(px[jj], py[jj], pz[jj], sx, sy, sz);
-                                float d2;
-                                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(td[jj]));
-                                td[jj] = d2;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // new table entries for the groups whose running minima may have changed
-#pragma unroll
-        for (int g4 = 0; g4 < G; g4 += 4) {
-            if (((touched >> g4) & 15u) == 0) continue;                   // wave-uniform
-#pragma unroll
-            for (int gu = 0; gu < 4; ++gu) {
-                    const int g = g4 + gu;
-                if (touched & (1u << g)) {                                // wave-uniform
-                    // this lane's candidate: the first of its maxima in slot order (ascending tie keys, strict >)
-                    float lbest = -1.0f;
-                    int bs = 0;
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const bool gt = td[g * S + i] > lbest;
-                        bs = gt ? i : bs;
-                        lbest = gt ? td[g * S + i] : lbest;
-                    }
-                    const bool real = lbest >= 0.f;                       // this lane owns a real point of the group
-                    const uint32_t bits = real ? __float_as_uint(lbest) : 0u;
-                    const float mx = fps_sel<S>(px + g * S, bs), my = fps_sel<S>(py + g * S, bs), mz = fps_sel<S>(pz + g * S, bs);
-                    uint32_t mk = 0;
-                    float other = -1.0f;                                   // the largest of its other slots
-#pragma unroll
-                    for (int i = 0; i < S; ++i) {
-                        const int jj = g * S + i;
-                        const uint32_t ki = (jj & 1) ? kk[jj / 2] >> 16 : kk[jj / 2] & 0xFFFFu;
-                        mk = bs == i ? ki : mk;
-                        other = bs != i ? fmaxf(other, td[jj]) : other;
-                    }
-                    const uint32_t wmax = dclr_wave_max_u32(bits);
-                    const uint64_t hit = __ballot(real && bits == wmax);
-                    int wl;
-                    if ((hit & (hit - 1)) == 0) wl = __builtin_ctzll(hit);   // one lane holds the maximum (the usual case)
-                    else {                                                // exact tie: smallest tie key among the holders
-                        const uint32_t key = (real && bits == wmax) ? fps_tk1024(mk) : 0xFFFFFFFFu;
-                        const uint32_t wkey = dclr_wave_min_u32(key);
-                        wl = __builtin_ctzll(__ballot(key == wkey));
-                    }
-                    // runner-up: every other lane's best, and in the winner's lane its other slots
-                    const float alt = lane == wl ? other : lbest;
-                    const uint32_t ru = dclr_wave_max_u32(alt < 0.f ? 0u : __float_as_uint(alt));
-                    const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)mk, wl);
-                    const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mx), wl));
-                    const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(my), wl));
-                    const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(mz), wl));
-                    if (lane == g) {
-                        o_val = wmax; o_tk = fps_tk1024(wk); o_ru = ru; o_k = wk;
-                        o_x = wx; o_y = wy; o_z = wz;
-                    }
-                }
-            }
-        }
-        if (lane < G) {
-            gtab[par][wave * G + lane][0] = make_uint4(o_val, o_tk, o_ru, o_k);
-            gtab[par][wave * G + lane][1] = make_uint4(__float_as_uint(o_x), __float_as_uint(o_y), __float_as_uint(o_z), 0u);
-        }
-        __syncthreads();
-        const int le = lane < NG ? lane : 0;
-        const uint4 e0 = gtab[par][le][0], e1 = gtab[par][le][1];
-        uint32_t v = lane < NG ? e0.x : 0u, tk = lane < NG ? e0.y : 0xFFFFFFFFu;
-        uint32_t ru_acc[J];
-        float qx[J] = {0.f, 0.f, 0.f, 0.f}, qy[J] = {0.f, 0.f, 0.f, 0.f}, qz[J] = {0.f, 0.f, 0.f, 0.f};
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            if (r + j >= m) break;                                        // uniform
-            const uint32_t m_hi = dclr_wave_max_u32(v);
-            const uint64_t holders = __ballot(v == m_hi);
-            int wid;
-            if ((holders & (holders - 1)) == 0) wid = __builtin_ctzll(holders);
-            else {
-                const uint32_t kmin = dclr_wave_min_u32(v == m_hi ? tk : 0xFFFFFFFFu);
-                wid = __builtin_ctzll(__ballot(v == m_hi && tk == kmin));
-            }
-            const float x = __uint_as_float(__builtin_amdgcn_readlane(e1.x, wid));
-            const float y = __uint_as_float(__builtin_amdgcn_readlane(e1.y, wid));
-            const float z = __uint_as_float(__builtin_amdgcn_readlane(e1.z, wid));
-            bool ok = true;
-#pragma unroll
-            for (int i = 0; i < j; ++i) {
-                const uint32_t dist = __float_as_uint(dclr_sqdist(x, y, z, qx[i], qy[i], qz[i]));
-                ok = ok && m_hi > ru_acc[i] && dist >= m_hi;
-            }
-            if (!ok) break;                                               // uniform (never for j == 0)
-            qx[j] = x; qy[j] = y; qz[j] = z;
-            ru_acc[j] = (uint32_t)__builtin_amdgcn_readlane((int)e0.z, wid);
-            if (t == 0) picked[r + j] = __builtin_amdgcn_readlane((int)e0.w, wid);
-            cnt = j + 1;
-            const bool mine = lane == wid;
-            v = mine ? 0u : v;
-            tk = mine ? 0xFFFFFFFFu : tk;
-        }
-        np = cnt;
-#pragma unroll
-        for (int j = 0; j < J; ++j) { pcx[j] = qx[j]; pcy[j] = qy[j]; pcz[j] = qz[j]; }
-        r += cnt;
-        par ^= 1;
-        sr += 1;
-    }
-    __syncthreads();
-    for (int i = t; i < m; i += 256) idx[i] = picked[i];
-    if (t == 0) group_box[6] = (float)sr;                                 // diagnostics: barrier rounds this cloud took
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1856,29 +1206,19 @@ void launch_reg(int b, int n, int pstride, int m, const float *pts, float *temp,
                        pstride, m, pts, temp, idx, (uint32_t)(T - 1), (uint32_t)log2t);
 }
 
-template <int WGS, int P, int G, int FORCE_MODE = -1>
+template <int WGS, int P, int G>
 void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, float4 *group_pts,
                    float *group_box, hipStream_t s) {
     constexpr int NP = WGS * P;
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
     // A/B switches: DCLR_FPS_SINGLE = one sample per barrier round, DCLR_FPS_WAVECAND = several with per-wave candidates
-    static const int env_mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_GROUPCAND16") ? 2 : getenv("DCLR_FPS_WAVECAND") ? 1 : 4;
-    const int mode = FORCE_MODE >= 0 ? FORCE_MODE : env_mode;
-    if (mode == 3)
-        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 3>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
-    else if (mode == 0)
+    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
+    if (mode == 0)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 0>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
-    else if (mode == 1)
-        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
-    else if (mode == 2)
-        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 2>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
     else
-        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 4>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
 }
 
@@ -1983,31 +1323,6 @@ extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *
     DCLR_REQUIRE(c >= 3 && group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
     int ng, gs;
     if (!fps_group_layout(n, &ng, &gs) || getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
-    // Opt-in (DCLR_FPS_QUAD=1): measured SLOWER than the 16-wave kernel (1567 vs 894 us per 64 clouds of 16384 points,
-    // 560 vs 440 us per 512 clouds of 2048): with one wave per SIMD nothing hides the latency of the serial
-    // select / recompute chain.
-    static const bool quad = getenv("DCLR_FPS_QUAD") && atoi(getenv("DCLR_FPS_QUAD")) == 1;
-    if (!quad || (size_t)m * sizeof(int32_t) > 48 * 1024)
-        return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
-                            group_box);
-    // two launches: the spatial partition (kernel A' in partition-only mode: 1024 threads, ~25 us), then the sampling
-    // rounds on four waves per cloud reading it back (kernel A'')
-    DCLR_REQUIRE(b > 0 && n > 0 && m > 0 && clouds && idx);
-    hipStream_t s = (hipStream_t)stream;
-    float4 *gp = reinterpret_cast<float4 *>(group_pts);
-    const size_t lds_m = (size_t)m * sizeof(int32_t);
-    if (n <= 2048) {
-        launch_pruned<1024, 2, 2, 3>(b, n, c, m, clouds, nullptr, idx, gp, group_box, s);
-        hipLaunchKernelGGL((fps_quad_kernel<8, 8>), dim3(b), dim3(256), lds_m, s, n, c, m, clouds, idx, gp, group_box);
-    } else if (n <= 4096) {
-        launch_pruned<1024, 4, 4, 3>(b, n, c, m, clouds, nullptr, idx, gp, group_box, s);
-        hipLaunchKernelGGL((fps_quad_kernel<16, 16>), dim3(b), dim3(256), lds_m, s, n, c, m, clouds, idx, gp, group_box);
-    } else if (n <= 8192) {
-        launch_pruned<1024, 8, 4, 3>(b, n, c, m, clouds, nullptr, idx, gp, group_box, s);
-        hipLaunchKernelGGL((fps_quad_kernel<32, 16>), dim3(b), dim3(256), lds_m, s, n, c, m, clouds, idx, gp, group_box);
-    } else {
-        launch_pruned<1024, 16, 4, 3>(b, n, c, m, clouds, nullptr, idx, gp, group_box, s);
-        hipLaunchKernelGGL((fps_quad_kernel<64, 16>), dim3(b), dim3(256), lds_m, s, n, c, m, clouds, idx, gp, group_box);
-    }
-    return dclr_launch_status();
+    return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
+                        group_box);
 }

@@ -99,7 +99,9 @@ int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *id
  * pruning: every cloud is split into n_groups compact groups of group_size points
  * (dclr_fps_group_layout; available for 1024 < n <= 16384, otherwise DCLR_E_UNSUPPORTED).
  * group_pts (b, n_groups*group_size, 4) f32: x y z and the point index as raw u32 bits (0xFFFFFFFF =
- * padding slot, coordinates 3e38); group_box (b, n_groups, 8) f32: min xyz, max xyz, 0, 0.
+ * padding slot, coordinates 3e38); group_box (b, n_groups, 8) f32: min xyz, max xyz, 0, 0 -- except
+ * group_box[cloud][0][6], which receives the number of barrier rounds the cloud's sampling took (diagnostics:
+ * (m - 1) / rounds = samples per round).
  * dclr_sa_msg_fused uses them to skip the exhaustive ball-query sweep. */
 int dclr_fps_group_layout(int n, int *n_groups, int *group_size);
 /* Large clouds (16384 < n <= 65536): same samples through a spatially pruned kernel whose sorted points and
