@@ -78,40 +78,21 @@ struct HrRing {
     char *ring;          // LDS ring base
     int slot;            // ring slot of the stage whose first half is already in `xa`
     int dma_slot;        // where the next DMA goes
-    int rot;             // tile-group rotation of this workgroup (see hr_next_stage)
-    int dl, dt, ds;      // DMA cursor: layer, tile-group iteration, k-step of the next stage to fetch
+    int dma_stage;       // the next stage to fetch (stages are consumed in stream order; past the end: the zero stage)
     unsigned long long t_last, t_a, t_dma, t_b;     // ABL & 4 (diagnostic build): cycle sums per stage segment
 };
 
 __device__ unsigned long long hr_dbg[16];
 #define HR_STAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 
-// Stage the DMA cursor points at, then advance it. Every workgroup walks a layer's tile groups in its own
-// rotation: (iteration + rot) mod NTG. All workgroups of an XCD stream the same 4.2 MB, which its L2 (4 MB) cannot
-// hold across passes, so whoever is ahead pays the fabric latency for every line and the others wait on the same
-// fills -- measured: 128 workgroups in lockstep moved 47 GB/s each with 80 KB in flight, i.e. ~1.7 us per fill,
-// whether the fragments went to registers (head16_kernel) or through this ring. With rotated orders the workgroups
-// of an XCD lead different regions of a layer at the same time and find the rest already in L2.
-__device__ __forceinline__ int hr_next_stage(HrRing &r) {
-    if (r.dl >= HR_NL) return HR_STAGES;                                  // past the end: a padding stage (zeros)
-    const int ks = r.dl == 0 ? 9 : (r.dl < 3 ? 8 : 16);
-    const int ntg = r.dl < 2 ? 2 : (r.dl < 4 ? 4 : 8);
-    const int base = r.dl == 0 ? 0 : r.dl == 1 ? 18 : r.dl == 2 ? 34 : r.dl == 3 ? 66 : 130;
-    const int stage = base + ((r.dt + r.rot) & (ntg - 1)) * ks + r.ds;
-    if (++r.ds == ks) {
-        r.ds = 0;
-        if (++r.dt == ntg) { r.dt = 0; ++r.dl; }
-    }
-    return stage;
-}
-
 // this wave's quarter of the next stage -> ring slot dma_slot (4 x 1 KB, one LDS-DMA instruction each)
 __device__ __forceinline__ void hr_dma(HrRing &r, int wave) {
-    const int stage = hr_next_stage(r);
+    const int stage = r.dma_stage < HR_STAGES ? r.dma_stage : HR_STAGES;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         __builtin_amdgcn_global_load_lds((hr_gptr)(r.wq + (size_t)stage * HR_STAGE + q * 1024),
                                          (hr_lptr)(r.ring + r.dma_slot * HR_STAGE + (4 * wave + q) * 1024), 16, 0, 0);
+    r.dma_stage += 1;
     r.dma_slot = r.dma_slot + 1 == HR_R ? 0 : r.dma_slot + 1;
 }
 
@@ -209,20 +190,9 @@ __device__ __forceinline__ void hr_stage(HrRing &r, dclr_h8 (&xa)[4][2], const d
 
 // LDS atomic max behind the compiler's back: hipcc orders every LDS access it cannot prove disjoint from an LDS-DMA
 // destination behind `s_waitcnt vmcnt(0)`, which would drain the weight ring 256 times per workgroup.
-__device__ __forceinline__ void hr_lds_max_u32(float *p, float v) {
+__device__ __forceinline__ void hr_lds_max_u32(float *p, uint32_t v) {
     const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)p;
-    asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(__float_as_uint(v)) : "memory");
-}
-
-// max over the 16 lanes of a DPP row (the 16 points of this wave), result in every lane's copy of lane 15 ... we only
-// need it in one lane per row: lane 15 of each row after the inclusive scan
-__device__ __forceinline__ float hr_row_max(float v) {
-    const float ninf = -3.0e38f;
-    v = fmaxf(v, __uint_as_float(dclr_dpp<DCLR_DPP_ROW_SHR(1), 0xf>(__float_as_uint(ninf), __float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(dclr_dpp<DCLR_DPP_ROW_SHR(2), 0xf>(__float_as_uint(ninf), __float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(dclr_dpp<DCLR_DPP_ROW_SHR(4), 0xf>(__float_as_uint(ninf), __float_as_uint(v))));
-    v = fmaxf(v, __uint_as_float(dclr_dpp<DCLR_DPP_ROW_SHR(8), 0xf>(__float_as_uint(ninf), __float_as_uint(v))));
-    return v;
+    asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // One layer: NTG tile groups of 128 output channels, KS k-steps each. Hidden layers leave the next layer's B
@@ -232,8 +202,7 @@ __device__ __forceinline__ void hr_layer(HrRing &r, dclr_h8 (&xa)[4][2], const H
                                          const float *bias_s, float *cm_wave, int lane, int wave) {
     const int g = lane >> 4;
 #pragma unroll 1
-    for (int it = 0; it < NTG; ++it) {
-        const int tg = (it + r.rot) & (NTG - 1);                // the tile group this iteration's stages hold
+    for (int tg = 0; tg < NTG; ++tg) {
         dclr_f32x4 acc[8], acc2[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -250,17 +219,22 @@ __device__ __forceinline__ void hr_layer(HrRing &r, dclr_h8 (&xa)[4][2], const H
 #pragma unroll
         for (int s = 0; s < KS; ++s) hr_stage<ABL>(r, xa, in[s].hi, in[s].lo, acc, acc2, lane, wave);
         if constexpr (LAST) {
-            // lane = point, registers = channels: max over this wave's 16 points is a DPP row reduction; bias and
-            // ReLU commute with the maximum, and the non-negative results fold across waves as unsigned integers
+            // lane = point, registers = channels: bias and ReLU first (they commute with the maximum), then the values are
+            // non-negative and the maximum over this wave's 16 points is four one-instruction u32 DPP steps per value;
+            // lane 15 of each row then folds its 32 results into the workgroup's column maxima (one masked block)
+            uint32_t mrow[8][4];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const int ch = 128 * tg + 16 * t + 4 * g;
-                const dclr_f32x4 bv = *reinterpret_cast<const dclr_f32x4 *>(bias_s + ch);
+                const dclr_f32x4 bv = *reinterpret_cast<const dclr_f32x4 *>(bias_s + 128 * tg + 16 * t + 4 * g);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m = fmaxf(hr_row_max(fmaf(acc2[t][i], DCLR_SPLIT_INV, acc[t][i])) + bv[i], 0.f);
-                    if ((lane & 15) == 15) hr_lds_max_u32(cm_wave + ch + i, m);
-                }
+                for (int i = 0; i < 4; ++i)
+                    mrow[t][i] = dclr_row16_max_lanes(__float_as_uint(fmaxf(fmaf(acc2[t][i], DCLR_SPLIT_INV, acc[t][i]) + bv[i], 0.f)));
+            }
+            if ((lane & 15) == 15) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hr_lds_max_u32(cm_wave + 128 * tg + 16 * t + 4 * g + i, mrow[t][i]);
             }
         } else {
 #pragma unroll
@@ -295,8 +269,7 @@ template <int ABL>
 __global__ __launch_bounds__(HR_WAVES * 64, 1) void head_reg_kernel(const float *__restrict__ x, int ldx, int k_in,
                                                                     const char *__restrict__ wq,
                                                                     const float *__restrict__ bias,
-                                                                    float *__restrict__ colmax, int rows_per_group,
-                                                                    int rot_shift) {
+                                                                    float *__restrict__ colmax, int rows_per_group) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char *ring = lds;
     float *bias_s = reinterpret_cast<float *>(lds + HR_R * HR_STAGE);
@@ -309,8 +282,7 @@ __global__ __launch_bounds__(HR_WAVES * 64, 1) void head_reg_kernel(const float 
     HrRing r;
     r.wq = wq + (4 * wave) * 1024 + lane * 16;
     r.ring = ring;
-    r.rot = rot_shift < 0 ? 0 : (int)(blockIdx.x >> rot_shift);   // blocks b, b + 8, ... share an XCD: consecutive rotations
-    r.dl = 0; r.dt = 0; r.ds = 0;
+    r.dma_stage = 0;
     r.t_a = r.t_dma = r.t_b = 0;
     unsigned long long t_begin = 0;
     if constexpr (ABL & 4) { HR_STAMP(t_begin); }
@@ -429,7 +401,6 @@ extern "C" int dclr_head_conv_reg_f16(int m, int k_in, const void *packed, const
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return dclr_launch_status();
     static const int abl = getenv("DCLR_HR_ABL") ? atoi(getenv("DCLR_HR_ABL")) : 0;        // measurement switches
-    static const int rot = getenv("DCLR_HR_ROT") ? atoi(getenv("DCLR_HR_ROT")) : 3;
     auto launch = [&](auto kern) -> int {
         if (!granted[dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, HR_LDS) !=
@@ -438,7 +409,7 @@ extern "C" int dclr_head_conv_reg_f16(int m, int k_in, const void *packed, const
             granted[dev] = true;
         }
         hipLaunchKernelGGL(kern, dim3(m / HR_ROWS), dim3(HR_WAVES * 64), HR_LDS, (hipStream_t)stream, x, ldx, k_in,
-                           reinterpret_cast<const char *>(packed), bias, colmax, rows_per_group, rot);
+                           reinterpret_cast<const char *>(packed), bias, colmax, rows_per_group);
         return dclr_launch_status();
     };
     if (abl == 4) return launch(head_reg_kernel<4>);

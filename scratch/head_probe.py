@@ -3,6 +3,7 @@ one (head_reg_kernel), interleaved rounds in one process, HIP events on the laun
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ.setdefault('DCLR_HEAD_REG', '1')
 from deepclr_amd import ops, synthetic
 from deepclr_amd.config import model_config_from_dict
 from deepclr_amd.models import build_model

@@ -2,6 +2,7 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault('DCLR_HEAD_REG', '1')
 from deepclr_amd import ops, synthetic, lib
 from deepclr_amd.config import model_config_from_dict
 from deepclr_amd.models import build_model
