@@ -930,7 +930,7 @@ template <int NG>
 __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int m, const float *__restrict__ pts,
                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
                                                          float *__restrict__ std_all, uint32_t *__restrict__ sidx_all,
-                                                         uint16_t *__restrict__ cell_all) {
+                                                         uint16_t *__restrict__ cell_all, float *__restrict__ group_box) {
     constexpr int WGS = 1024, NW = 16, P = 4 * NG, NP = WGS * P, BINS = 4096;
     typedef typename VecOf<NG>::type gvec;
     __shared__ unsigned long long cell[3];
@@ -947,6 +947,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     float *std_ = std_all + (size_t)blockIdx.x * NP;
     uint32_t *sidx = sidx_all + (size_t)blockIdx.x * NP;
     uint16_t *cellof = cell_all + (size_t)blockIdx.x * NP;
+    if (group_box) group_box += (size_t)blockIdx.x * NW * NG * 8;
 
     // ---- 1. bounding box ------------------------------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -1050,7 +1051,9 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         bool any = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;    // -2: padding can never beat best = -1
+            // padding: far away (set abstraction reads these groups too: distance +inf, never inside a ball) and
+            // running minimum -2, which no update raises and which never beats best = -1
+            float x = 3.0e38f, y = 3.0e38f, z = 3.0e38f, d = -2.0f;
             uint32_t k = 0xFFFFFFFFu;
             if (tk[i] != 0xFFFFFFFFu) {
                 k = fps_tk1024_inv(tk[i]);
@@ -1065,11 +1068,17 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             spts[base + 64 * i] = make_float4(x, y, z, __uint_as_float(k));
             std_[base + 64 * i] = d;
         }
+        float box[6];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float l = fps_shfl_min(blo[a]), h = fps_shfl_max(bhi[a]);
             if (lane == g) { glo[a] = l; ghi[a] = h; }
+            box[a] = l; box[3 + a] = h;
         }
+        if (group_box && lane < 8)
+            group_box[(size_t)(wave * NG + g) * 8 + lane] =
+                lane == 0 ? box[0] : lane == 1 ? box[1] : lane == 2 ? box[2] : lane == 3 ? box[3]
+                : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         vec_set<NG>(gbest, g, any ? 0.f : -1.0f);
         if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
     }
@@ -1222,9 +1231,11 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
                            group_pts, group_box);
 }
 
-// Spatial groups the pruned kernel forms (and can export): 16 waves x G groups of 64 * (P / G) points.
+// Spatial groups the pruned kernel forms (and can export): NW waves x G groups of 64 * (P / G) points.
 bool fps_group_layout(int n, int *n_groups, int *group_size) {
-    if (n <= 1024 || n > 16384) return false;
+    if (n <= 1024 || n > 65536) return false;
+    if (n > 16384) { *n_groups = n <= 32768 ? 128 : 256; *group_size = 256; return true; }   // workspace kernel: 16 waves x NG
+    if (n <= 2048) { *n_groups = 32; *group_size = 64; return true; }      // 8 waves x 4 groups of one slot
     const int p = n <= 2048 ? 2 : n <= 4096 ? 4 : n <= 8192 ? 8 : 16;
     const int g = p >= 4 ? 4 : p;
     *n_groups = 16 * g;
@@ -1238,7 +1249,9 @@ int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp
     if ((size_t)m * sizeof(int32_t) > 64 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
     static const bool plain = getenv("DCLR_FPS_PLAIN") != nullptr;             // A/B switch for measurements
     if (!plain && n > 1024 && n <= 16384) {
-        if (n <= 2048) launch_pruned<1024, 2, 2>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
+        // 2048 points: 8 waves x 4 points per lane and two clouds per CU (422 vs 445 us for 512 clouds; 4 waves x 8
+        // points, six clouds per CU: 490 -- a round costs the same ~4.6 k cycles whatever the wave count)
+        if (n <= 2048) launch_pruned<512, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
         else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
         else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
         else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
@@ -1291,26 +1304,34 @@ extern "C" long long dclr_fps_workspace_bytes(int b, int n) {
     return (long long)(fps_ws_bytes_per_cloud(n) * (size_t)b);
 }
 
+// Workspace sampler (16384 < n <= 65536). `spts` = the sorted points (float4 x, y, z, index bits; 1024 * P per cloud): a
+// slice of the workspace, or the caller's group_pts buffer when the groups are exported for set abstraction.
+static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int32_t *idx, float4 *spts, char *rest,
+                            float *group_box, hipStream_t stream) {
+    if ((size_t)m * sizeof(int32_t) > 32 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] shares LDS with the histogram
+    const size_t np = n <= 32768 ? 32768 : 65536;
+    float *stdv = reinterpret_cast<float *>(rest);
+    uint32_t *sidx = reinterpret_cast<uint32_t *>(rest + (size_t)b * np * 4);
+    uint16_t *cells = reinterpret_cast<uint16_t *>(rest + (size_t)b * np * 8);
+    if (np == 32768)
+        hipLaunchKernelGGL((fps_paged_kernel<8>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream,
+                           n, c, m, clouds, idx, spts, stdv, sidx, cells, group_box);
+    else
+        hipLaunchKernelGGL((fps_paged_kernel<16>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream,
+                           n, c, m, clouds, idx, spts, stdv, sidx, cells, group_box);
+    return dclr_launch_status();
+}
+
 extern "C" int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx, void *workspace,
                                   long long workspace_bytes, dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3 && b > 0 && n > 0 && m > 0 && clouds && idx);
     const size_t need = fps_ws_bytes_per_cloud(n) * (size_t)b;
     if (need == 0 || getenv("DCLR_FPS_PLAIN")) return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream);
     DCLR_REQUIRE(workspace && workspace_bytes >= (long long)need && ((uintptr_t)workspace & 15) == 0);
-    if ((size_t)m * sizeof(int32_t) > 32 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] shares LDS with the histogram
     const size_t np = n <= 32768 ? 32768 : 65536;
     char *w = static_cast<char *>(workspace);
-    float4 *spts = reinterpret_cast<float4 *>(w);
-    float *stdv = reinterpret_cast<float *>(w + (size_t)b * np * 16);
-    uint32_t *sidx = reinterpret_cast<uint32_t *>(w + (size_t)b * np * 20);
-    uint16_t *cells = reinterpret_cast<uint16_t *>(w + (size_t)b * np * 24);
-    if (np == 32768)
-        hipLaunchKernelGGL((fps_paged_kernel<8>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), (hipStream_t)stream,
-                           n, c, m, clouds, idx, spts, stdv, sidx, cells);
-    else
-        hipLaunchKernelGGL((fps_paged_kernel<16>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), (hipStream_t)stream,
-                           n, c, m, clouds, idx, spts, stdv, sidx, cells);
-    return dclr_launch_status();
+    return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(w), w + (size_t)b * np * 16, nullptr,
+                            (hipStream_t)stream);
 }
 
 extern "C" int dclr_fps_group_layout(int n, int *n_groups, int *group_size) {
@@ -1318,10 +1339,23 @@ extern "C" int dclr_fps_group_layout(int n, int *n_groups, int *group_size) {
     return fps_group_layout(n, n_groups, group_size) ? DCLR_OK : DCLR_E_UNSUPPORTED;
 }
 
+extern "C" int dclr_fps_clouds_grouped_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx,
+                                          float *group_pts, float *group_box, void *workspace, long long workspace_bytes,
+                                          dclr_stream_t stream) {
+    DCLR_REQUIRE(c >= 3 && b > 0 && n > 16384 && n <= 65536 && m > 0 && clouds && idx && group_pts && group_box &&
+                 ((uintptr_t)group_pts & 15) == 0);
+    if (getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
+    const size_t np = n <= 32768 ? 32768 : 65536;
+    DCLR_REQUIRE(workspace && workspace_bytes >= (long long)((size_t)b * np * 10) && ((uintptr_t)workspace & 15) == 0);
+    return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(group_pts), static_cast<char *>(workspace),
+                            group_box, (hipStream_t)stream);
+}
+
 extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,
                                        float *group_pts, float *group_box, dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3 && group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
     int ng, gs;
+    if (n > 16384) return DCLR_E_UNSUPPORTED;                     // larger clouds: dclr_fps_clouds_grouped_ws
     if (!fps_group_layout(n, &ng, &gs) || getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
     return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
                         group_box);

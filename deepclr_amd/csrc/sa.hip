@@ -178,7 +178,7 @@ __device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz
 }
 
 
-template <int C>
+template <int C, int NCH>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                                                                const float *__restrict__ clouds,
                                                                const int32_t *__restrict__ fps_idx,
@@ -251,16 +251,25 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
     bool need_sweep = prm.group_pts == nullptr;
     if (prm.group_pts != nullptr) {
         const float4 *gp = prm.group_pts + bi * (size_t)prm.n_groups * prm.group_size;
-        const float *gb = prm.group_box + (bi * prm.n_groups + (lane < prm.n_groups ? lane : 0)) * 8;
-        const bool have = lane < prm.n_groups;             // n_groups <= 64: lane g owns group g's box
-        const float blx = have ? gb[0] : 3.0e38f, bly = have ? gb[1] : 3.0e38f, blz = have ? gb[2] : 3.0e38f;
-        const float bhx = have ? gb[3] : -3.0e38f, bhy = have ? gb[4] : -3.0e38f, bhz = have ? gb[5] : -3.0e38f;
+        // lane g owns the boxes of groups g, 64 + g, ... (NCH chunks of 64 groups: 1 for the register sampler's <= 64
+        // groups, 2 / 4 for the workspace sampler's 128 / 256)
+        float blx[NCH], bly[NCH], blz[NCH], bhx[NCH], bhy[NCH], bhz[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const bool have = ch * 64 + lane < prm.n_groups;
+            const float *gb = prm.group_box + (bi * prm.n_groups + (have ? ch * 64 + lane : 0)) * 8;
+            blx[ch] = have ? gb[0] : 3.0e38f; bly[ch] = have ? gb[1] : 3.0e38f; blz[ch] = have ? gb[2] : 3.0e38f;
+            bhx[ch] = have ? gb[3] : -3.0e38f; bhy[ch] = have ? gb[4] : -3.0e38f; bhz[ch] = have ? gb[5] : -3.0e38f;
+        }
         const int slices = prm.group_size / 64;
 #pragma unroll 1
         for (int c = 0; c < n_live; ++c) {
             const float cx = sa_cxyz[wave][c][0], cy = sa_cxyz[wave][c][1], cz = sa_cxyz[wave][c][2];
-            const float lbv = sa_box_lower_bound(blx, bly, blz, bhx, bhy, bhz, cx, cy, cz);
-            const uint64_t gmask = __ballot(have && lbv < prm.radius2_max);
+            uint64_t gm[NCH];          // groups the largest ball can reach, per chunk (an absent group's bound is +inf)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                gm[ch] = __ballot(sa_box_lower_bound(blx[ch], bly[ch], blz[ch], bhx[ch], bhy[ch], bhz[ch], cx, cy, cz) <
+                                  prm.radius2_max);
             // One pass: neighbours are staged for the MLP as they are found (any order) and counted. If a cap
             // turns out to be exceeded -- index order then decides which nsample neighbours count -- or the
             // ring would overflow, the centroid's entries are taken back (nothing of it has been drained:
@@ -269,11 +278,11 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
             // use: one slice at a time the scan is a chain of ~250 dependent L2 round trips per wave.
             int n1[SA_MAX_SCALES] = {0, 0};
             const int q0[SA_MAX_SCALES] = {qn[0], qn[1]};
-            auto load_pair = [&](uint64_t &m, float4 (&q)[8], int &nq) {
-                const int ga = __builtin_ctzll(m);
+            auto load_pair = [&](uint64_t &m, int g0, float4 (&q)[8], int &nq) {
+                const int ga = g0 + __builtin_ctzll(m);
                 m &= m - 1;
                 const bool two = m != 0;
-                const int gbb = two ? __builtin_ctzll(m) : ga;
+                const int gbb = two ? g0 + __builtin_ctzll(m) : ga;
                 if (two) m &= m - 1;
                 const float4 *pa = gp + (size_t)ga * prm.group_size + lane;
                 const float4 *pb = gp + (size_t)gbb * prm.group_size + lane;
@@ -286,10 +295,18 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 nq = two ? 8 : 4;
             };
             bool over = false;
-            for (uint64_t m = gmask; m != 0 && !over;) {
+            int ch = 0;
+            for (uint64_t m = gm[0]; !over;) {
+                if constexpr (NCH > 1) {
+                    while (m == 0 && ch + 1 < NCH) {           // next chunk of 64 groups (wave-uniform)
+                        ++ch;
+                        m = ch == 1 ? gm[1] : ch == 2 ? gm[NCH > 2 ? 2 : 0] : gm[NCH > 3 ? 3 : 0];
+                    }
+                }
+                if (m == 0) break;
                 float4 q[8];
                 int nq;
-                load_pair(m, q, nq);
+                load_pair(m, ch * 64, q, nq);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if ((u & 3) >= slices || u >= nq) continue;            // clamped duplicate of another slice (uniform)
@@ -484,18 +501,19 @@ extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *c
     }
     if (group_pts || group_box) {
         DCLR_REQUIRE(group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
-        if (dclr_fps_group_layout(n, &prm.n_groups, &prm.group_size) != DCLR_OK || prm.n_groups > 64) return DCLR_E_INVALID;
+        if (dclr_fps_group_layout(n, &prm.n_groups, &prm.group_size) != DCLR_OK || prm.n_groups > 256) return DCLR_E_INVALID;
         prm.group_pts = reinterpret_cast<const float4 *>(group_pts);
         prm.group_box = group_box;
     }
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);
-    if (c == 4)
-        hipLaunchKernelGGL((sa_msg_kernel<4>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,
-                           fps_idx, out_rows, counts);
-    else
-        hipLaunchKernelGGL((sa_msg_kernel<3>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,
-                           fps_idx, out_rows, counts);
+    const int nch = prm.n_groups <= 64 ? 1 : prm.n_groups <= 128 ? 2 : 4;      // chunks of 64 group boxes per lane
+#define SA_LAUNCH(C_, NCH_)                                                                                          \
+    hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,    \
+                       fps_idx, out_rows, counts)
+    if (c == 4) { if (nch == 1) SA_LAUNCH(4, 1); else if (nch == 2) SA_LAUNCH(4, 2); else SA_LAUNCH(4, 4); }
+    else        { if (nch == 1) SA_LAUNCH(3, 1); else if (nch == 2) SA_LAUNCH(3, 2); else SA_LAUNCH(3, 4); }
+#undef SA_LAUNCH
     return dclr_launch_status();
 }
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     'dclr_fps_group_layout': [_i, _p, _p],
     'dclr_fps_workspace_bytes': [_i, _i],
     'dclr_fps_clouds_ws': [_i, _i, _i, _i, _p, _p, _p, ctypes.c_longlong, _p],
+    'dclr_fps_clouds_grouped_ws': [_i, _i, _i, _i, _p, _p, _p, _p, _p, ctypes.c_longlong, _p],
     'dclr_fps_clouds_grouped': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],

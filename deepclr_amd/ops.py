@@ -173,6 +173,14 @@ def fps_clouds_grouped(clouds: torch.Tensor, npoint: int):
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
     gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
     gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
+    if n > 16384:                        # workspace kernel: its sorted point list is group_pts itself
+        if npoint * 4 > 32 * 1024:
+            return fps_clouds(clouds, npoint), None, None
+        need = lib.load().dclr_fps_workspace_bytes(b, n)
+        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device)
+        _call('dclr_fps_clouds_grouped_ws', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(),
+              gpts.data_ptr(), gbox.data_ptr(), ws.data_ptr(), need, lib.stream_ptr())
+        return idx, gpts, gbox
     _call('dclr_fps_clouds_grouped', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
           gbox.data_ptr(), lib.stream_ptr())
     return idx, gpts, gbox

@@ -97,7 +97,8 @@ int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *id
 
 /* The same sampling, additionally exporting the spatial partition the kernel builds for its own
  * pruning: every cloud is split into n_groups compact groups of group_size points
- * (dclr_fps_group_layout; available for 1024 < n <= 16384, otherwise DCLR_E_UNSUPPORTED).
+ * (dclr_fps_group_layout; available for 1024 < n <= 65536, otherwise DCLR_E_UNSUPPORTED; clouds above
+ * 16384 points go through dclr_fps_clouds_grouped_ws).
  * group_pts (b, n_groups*group_size, 4) f32: x y z and the point index as raw u32 bits (0xFFFFFFFF =
  * padding slot, coordinates 3e38); group_box (b, n_groups, 8) f32: min xyz, max xyz, 0, 0 -- except
  * group_box[cloud][0][6], which receives the number of barrier rounds the cloud's sampling took (diagnostics:
@@ -112,6 +113,11 @@ int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *clouds, int32_t 
                        long long workspace_bytes, dclr_stream_t stream);
 int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,
                             float *group_pts, float *group_box, dclr_stream_t stream);
+/* The grouped form for 16384 < n <= 65536: the kernel's sorted point list IS group_pts (128 / 256 groups of 256
+ * points), so the workspace only has to hold the rest (any dclr_fps_workspace_bytes(b, n) buffer is enough). */
+int dclr_fps_clouds_grouped_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx,
+                               float *group_pts, float *group_box, void *workspace, long long workspace_bytes,
+                               dclr_stream_t stream);
 
 /* Set abstraction, multi-scale grouping, fused (reference: SetAbstraction.forward,
  * /root/reference/deepclr/models/deepclr.py:88-94, -> PointnetSAModuleMSG with use_xyz=True, bn=False):

@@ -194,6 +194,44 @@ def _check_set_abstraction(c, n, npoint, radii, nsamples, expect_cap=True):
         assert not expect_cap or (hits == ns).any() or r < 0.1
 
 
+@pytest.mark.parametrize('n, pairs', [(20000, 1), (32768, 1), (40000, 1), (65536, 2)])
+def test_large_cloud_groups_from_the_workspace_sampler(n, pairs):
+    """16384 < n <= 65536: the workspace sampler exports its 128 / 256 groups of 256 points and set abstraction takes
+    the grouped fast path over them: same samples as the ungrouped call, groups = a permutation of the cloud with
+    tight boxes, rows and counts bit-identical to the exhaustive sweep."""
+    cfg = synthetic.model_cfg('kitti')
+    sa = {k_: v[0] for k_, v in cfg['params']['cloud_features']['params'].items()}
+    x = torch.from_numpy(synthetic.make_batch('kitti', pairs, n, first_pair=41)).to(DEV)
+    npoint = int(sa['npoint'])
+    idx, gpts, gbox = ops.fps_clouds_grouped(x, npoint)
+    assert gpts is not None and ops.fps_group_layout(n) == ((128 if n <= 32768 else 256), 256)
+    assert torch.equal(idx, ops.fps_clouds(x, npoint))
+    k = gpts[..., 3].contiguous().view(torch.int32)
+    for b_ in range(x.shape[0]):
+        real = k[b_] >= 0
+        kk = k[b_][real].long()
+        assert torch.equal(torch.sort(kk).values, torch.arange(n, device=DEV))
+        assert torch.equal(gpts[b_][real][:, :3], x[b_, kk, :3])
+        assert bool((gpts[b_][~real][:, :3] == 3.0e38).all())
+        g = gpts[b_].view(-1, 256, 4)
+        for a in range(3):
+            col = g[:, :, a]
+            live = k[b_].view(-1, 256) >= 0
+            lo = torch.where(live, col, torch.full_like(col, 3.0e38)).min(dim=1).values
+            hi = torch.where(live, col, torch.full_like(col, -3.0e38)).max(dim=1).values
+            has = live.any(dim=1)
+            assert torch.equal(gbox[b_, :, a][has], lo[has]) and torch.equal(gbox[b_, :, 3 + a][has], hi[has])
+    from deepclr_amd.pointnet2 import PointnetSAModuleMSG
+    torch.manual_seed(9)
+    sam = PointnetSAModuleMSG(npoint=npoint, radii=list(sa['radii']), nsamples=list(sa['nsamples']),
+                              mlps=[[1, 16, 16, 32] for _ in sa['radii']], bn=False, use_xyz=True).to(DEV)
+    rows_a, counts_a = ops.sa_msg_fused(x, idx, list(sa['radii']), list(sa['nsamples']), sam.packed_mlps(), want_counts=True)
+    rows_b, counts_b = ops.sa_msg_fused(x, idx, list(sa['radii']), list(sa['nsamples']), sam.packed_mlps(),
+                                        want_counts=True, groups=(gpts, gbox))
+    assert torch.equal(counts_a, counts_b) and torch.equal(rows_a, rows_b)
+    assert int(counts_a.max()) > 1
+
+
 def test_radius_mask_is_exercised():
     """ModelNet arch: flow-embedding radius 0.2 with k = 30 of 512 points masks many neighbours."""
     cfg = synthetic.model_cfg('modelnet')
