@@ -502,7 +502,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         gbest[g] = any ? 0.f : -1.0f;
         gjj[g] = g * S;
-        if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
+        const bool group_any = __ballot(any) != 0;                               // all lanes vote: NOT inside `lane == g &&`
+        if (lane == g && group_any) gmaxv = __uint_as_float(0x7F800000u);        // +inf forces the first update
     }
     __syncthreads();                                       // `cellof` is dead: `picked` (same storage) may be written
 
@@ -917,6 +918,54 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     }
 }
 
+// Leader step of a several-samples round (see fps_pruned_kernel, MODE 1): one wave reads the 16 published per-wave
+// entries (lane & 15 = wave) and accepts the best candidate p1, then the best of the other waves p2 while
+// sqdist(p2, accepted) >= td[p2] and td[p2] exceeds the runner-up of every accepted sample's wave, and so on (<= J).
+// Writes picked[r..], plist[j] = coordinates, *plist_n = count.
+template <int J>
+__device__ __forceinline__ void fps_accept_samples(int par, int r, int m, int lane, unsigned long long (*wpk)[16],
+                                                   uint32_t (*wru)[16], FpsCand (*cand)[16], int32_t *picked,
+                                                   float (*plist)[4], int *plist_n) {
+    const unsigned long long e = wpk[par][lane & 15];
+    const uint32_t e_ru = wru[par][lane & 15];
+    const FpsCand w = cand[par][lane & 15];
+    uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
+    uint32_t ru_acc[J];
+    float qx[J], qy[J], qz[J];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        if (r + j >= m) break;                                    // uniform
+        const uint32_t m_hi = dclr_row16_max_u32(e_hi);
+        // the wave holding it: unique unless two waves tie on the value (then the key field decides)
+        const uint32_t holders = (uint32_t)__ballot(e_hi == m_hi) & 0xFFFFu;
+        int wid;
+        if ((holders & (holders - 1)) == 0) wid = __builtin_ctz(holders);
+        else wid = (int)(dclr_row16_max_u32(e_hi == m_hi ? e_lo : 0u) & 15u);
+        const float x = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.x), wid));
+        const float y = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.y), wid));
+        const float z = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w.z), wid));
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+            const uint32_t dist = __float_as_uint(dclr_sqdist(x, y, z, qx[i], qy[i], qz[i]));
+            ok = ok && m_hi > ru_acc[i] && dist >= m_hi;
+        }
+        if (!ok) break;
+        qx[j] = x; qy[j] = y; qz[j] = z;
+        ru_acc[j] = (uint32_t)__builtin_amdgcn_readlane((int)e_ru, wid);
+        if (lane == 0) {
+            picked[r + j] = __builtin_amdgcn_readlane(w.k, wid);
+            plist[j][0] = x; plist[j][1] = y; plist[j][2] = z;
+        }
+        cnt = j + 1;
+        const bool mine = (lane & 15) == wid;
+        e_hi = mine ? 0u : e_hi;
+        e_lo = mine ? 0u : e_lo;
+    }
+    if (lane == 0) *plist_n = cnt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Kernel B: clouds too large for one CU's registers (16384 < n <= 65536). Same sampling rule, same
 // spatial pruning as kernel A', but the sorted points and their running minima live in a global
@@ -926,7 +975,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 // group (registers) and which slot holds it (2 bits per group). A round then reads and writes ~10 % of
 // the cloud instead of all of it (fps_stream_kernel: 1 MB per round through one CU's memory path).
 // ------------------------------------------------------------------------------------------------
-template <int NG>
+template <int NG, int MODE>                       // MODE as in fps_pruned_kernel: 0 one sample per barrier round, 1 several
 __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int m, const float *__restrict__ pts,
                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
                                                          float *__restrict__ std_all, uint32_t *__restrict__ sidx_all,
@@ -935,6 +984,10 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     typedef typename VecOf<NG>::type gvec;
     __shared__ unsigned long long cell[3];
     __shared__ FpsCand cand[2][16];
+    __shared__ unsigned long long wpk[2][16];              // MODE 1: per-wave packed candidate, by round parity
+    __shared__ uint32_t wru[2][16];                        // MODE 1: per-wave runner-up value
+    __shared__ float plist[4][4];                          // MODE 1: the samples accepted for the next round
+    __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t hist[BINS];
@@ -1017,15 +1070,18 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ---- 3. groups: wave w owns sorted positions [w * 256 NG, (w + 1) * 256 NG); group g = 256 of them,
-    //         slot i of lane l = position base + 64 i + l, slots of a lane in ascending tie-key order ------
+    // ---- 3. groups: 256 consecutive sorted positions each; wave w owns groups w, 16 + w, 32 + w, ... (its
+    //         group g = global group 16 g + w): a sample touches a few spatially adjacent groups and every touched
+    //         group costs its wave a dependent round trip to the workspace, so neighbours go to different waves.
+    //         Slot i of lane l = position base + 64 i + l, slots of a lane in ascending tie-key order ------
     float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};   // lane g: box of group g
     float gmaxv = 0.f;
     gvec gbest;                                            // per lane: largest running minimum of the 4 slots
+    gvec gsec;                                             // MODE 1: the largest among the lane's other 3 slots
     uint32_t gslot = 0;                                    // 2 bits per group: the slot holding it
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-        const int base = (wave * NG + g) * 256 + lane;
+        const int base = (g * NW + wave) * 256 + lane;
         uint32_t tk[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1076,14 +1132,150 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             box[a] = l; box[3 + a] = h;
         }
         if (group_box && lane < 8)
-            group_box[(size_t)(wave * NG + g) * 8 + lane] =
+            group_box[(size_t)(g * NW + wave) * 8 + lane] =
                 lane == 0 ? box[0] : lane == 1 ? box[1] : lane == 2 ? box[2] : lane == 3 ? box[3]
                 : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         vec_set<NG>(gbest, g, any ? 0.f : -1.0f);
-        if (lane == g && __ballot(any) != 0) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
+        if constexpr (MODE == 1) vec_set<NG>(gsec, g, -1.0f);
+        const bool group_any = __ballot(any) != 0;                               // all lanes vote: NOT inside `lane == g &&`
+        if (lane == g && group_any) gmaxv = __uint_as_float(0x7F800000u);        // +inf forces the first update
     }
     // every thread re-reads only what it wrote itself (same positions): no further fence needed
 
+    if constexpr (MODE == 1) {
+        // ---- several samples per barrier round: the acceptance scheme of fps_pruned_kernel MODE 1, on GROUP-level
+        //      state. The workspace of a launch is larger than an XCD's L2, so every dependent access to it costs
+        //      ~1 us: a round makes exactly one -- the touched groups are read two at a time, ALL accepted samples are
+        //      applied (a sample whose box bound spares a group cannot change it: min is idempotent there), and while
+        //      the points are in registers the wave reduces the group's best point, its tie key and its second-best
+        //      value into lane g. Selecting the wave's candidate and runner-up is then a 16-lane reduction over
+        //      registers, with no fetch of the winner. gmaxv is the group's exact largest running minimum here. -------
+        constexpr int J = 3, B = 2;
+        if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
+        __syncthreads();
+        float pcx[J] = {pts[0]}, pcy[J] = {pts[1]}, pcz[J] = {pts[2]};
+        int np = 1;
+        if (t == 0) picked[0] = 0;
+        uint32_t gsv = 0u, gkey = 0xFFFFFFFFu;                 // lane g: second-best value bits, tie key of the best point
+        float gx = 0.f, gy = 0.f, gz = 0.f;                    // lane g: the best point of group g
+        int32_t gk = 0;
+        unsigned long long c_packed = (unsigned long long)wave;
+        uint32_t c_ru = 0u;
+        int sr = 0;
+        for (int r = 1; r < m;) {
+            uint32_t act = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (j >= np) break;                                       // wave-uniform
+                const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], pcx[j], pcy[j], pcz[j]);
+                act |= (uint32_t)__ballot(lane < NG && lbv < gmaxv);
+            }
+            if (act != 0) {                                               // wave-uniform
+                for (uint32_t rem = act; rem != 0;) {
+                    int gs[B];
+                    bool live[B];
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        live[u] = rem != 0;
+                        gs[u] = live[u] ? __builtin_ctz(rem) : gs[0];    // absent: a clamped repeat, results unused
+                        if (live[u]) rem &= rem - 1;
+                    }
+                    float4 q[B][4];
+                    float o[B][4];
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        const int base = (gs[u] * NW + wave) * 256 + lane;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { q[u][i] = spts[base + 64 * i]; o[u][i] = std_[base + 64 * i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < B; ++u) {
+                        if (!live[u]) break;                              // wave-uniform
+                        const int g = gs[u];
+                        const int base = (g * NW + wave) * 256 + lane;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            if (j >= np) break;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float d = dclr_sqdist(q[u][i].x, q[u][i].y, q[u][i].z, pcx[j], pcy[j], pcz[j]);
+                                asm("v_min_f32 %0, %1, %2" : "=v"(o[u][i]) : "v"(d), "v"(o[u][i]));
+                            }
+                        }
+                        // this lane: best slot (slots ascend in tie-key order, strict > keeps the first) and the rest
+                        float best = -1.0f, sec = -1.0f;
+                        float4 bq = q[u][0];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            std_[base + 64 * i] = o[u][i];
+                            const bool gt = o[u][i] > best;
+                            sec = fmaxf(sec, gt ? best : o[u][i]);
+                            bq.x = gt ? q[u][i].x : bq.x; bq.y = gt ? q[u][i].y : bq.y;
+                            bq.z = gt ? q[u][i].z : bq.z; bq.w = gt ? q[u][i].w : bq.w;
+                            best = gt ? o[u][i] : best;
+                        }
+                        // the group: largest value, its holder (ties by key), the largest value of everything else
+                        const uint32_t bbits = best < 0.f ? 0u : __float_as_uint(best);
+                        const uint32_t gmx = dclr_wave_max_u32(bbits);
+                        const bool holder = best >= 0.f && bbits == gmx;
+                        const uint64_t hl = __ballot(holder);
+                        int wl;
+                        if ((hl & (hl - 1)) == 0) {
+                            wl = __builtin_ctzll(hl);
+                        } else {
+                            const uint32_t key = holder ? fps_tk1024(__float_as_uint(bq.w)) : 0xFFFFFFFFu;
+                            const uint32_t kmin = dclr_wave_min_u32(key);
+                            wl = __builtin_ctzll(__ballot(key == kmin));
+                        }
+                        const float alt = lane == wl ? sec : best;
+                        const uint32_t g2 = dclr_wave_max_u32(alt < 0.f ? 0u : __float_as_uint(alt));
+                        const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.x), wl));
+                        const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.y), wl));
+                        const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.z), wl));
+                        const int32_t wk = __builtin_amdgcn_readlane(__float_as_int(bq.w), wl);
+                        if (lane == g) {
+                            gmaxv = __uint_as_float(gmx);
+                            gsv = g2;
+                            gkey = fps_tk1024((uint32_t)wk);
+                            gx = wx; gy = wy; gz = wz; gk = wk;
+                        }
+                    }
+                }
+                // the wave's candidate: largest group maximum, ties by key; runner-up: the other groups' maxima and the
+                // winner group's second-best
+                const bool has = lane < NG && gkey != 0xFFFFFFFFu;
+                const uint32_t vbits = has ? __float_as_uint(gmaxv) : 0u;
+                const uint32_t wmax = dclr_row16_max_u32(vbits);
+                const bool hold = has && vbits == wmax;
+                const uint32_t kmin = dclr_row16_min_u32(hold ? gkey : 0xFFFFFFFFu);
+                const int wgp = __builtin_ctzll(__ballot(hold && gkey == kmin));
+                c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - kmin) << 16) |
+                           (unsigned long long)wave;
+                // both parities: wave 0 finished reading the other parity's entries before the second barrier of the
+                // previous round
+                if (lane == wgp) {
+                    const FpsCand c{gk, gx, gy, gz};
+                    cand[0][wave] = c;
+                    cand[1][wave] = c;
+                }
+                c_ru = dclr_row16_max_u32(has ? (lane == wgp ? gsv : vbits) : 0u);
+            }
+            const int par = sr & 1;
+            if (lane == 0) {
+                wpk[par][wave] = c_packed;
+                wru[par][wave] = c_ru;
+            }
+            __syncthreads();
+            if (wave == 0) fps_accept_samples<J>(par, r, m, lane, wpk, wru, cand, picked, plist, &plist_n);
+            __syncthreads();
+            np = plist_n;
+#pragma unroll
+            for (int j = 0; j < J; ++j) { pcx[j] = plist[j][0]; pcy[j] = plist[j][1]; pcz[j] = plist[j][2]; }
+            r += np;
+            sr += 1;
+        }
+        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
+    } else {
     float cx = pts[0], cy = pts[1], cz = pts[2];
     if (t == 0) picked[0] = 0;
     unsigned long long c_packed = (unsigned long long)wave;
@@ -1097,7 +1289,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         if (act != 0) {                                           // wave-uniform
             for (uint32_t rem = act; rem != 0; rem &= rem - 1) {
                 const int g = __builtin_ctz(rem);
-                const int base = (wave * NG + g) * 256 + lane;
+                const int base = (g * NW + wave) * 256 + lane;
                 float4 q[4];
                 float o[4];
 #pragma unroll
@@ -1137,7 +1329,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 hg = eq ? g : hg;
             }
             // fetch the candidate point (position, original index) while the wave reduction runs
-            const float4 mine4 = spts[(wave * NG + hg) * 256 + 64 * (int)((gslot >> (2 * hg)) & 3u) + lane];
+            const float4 mine4 = spts[(hg * NW + wave) * 256 + 64 * (int)((gslot >> (2 * hg)) & 3u) + lane];
             const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
             const float wmaxf = __uint_as_float(wmax);
             const bool holder = lbest == wmaxf;
@@ -1157,7 +1349,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                     float4 c4 = mine4;
                     uint32_t kg = 0xFFFFFFFFu;
                     if (vec_get<NG>(gbest, g) == wmaxf) {
-                        c4 = spts[(wave * NG + g) * 256 + 64 * (int)((gslot >> (2 * g)) & 3u) + lane];
+                        c4 = spts[(g * NW + wave) * 256 + 64 * (int)((gslot >> (2 * g)) & 3u) + lane];
                         kg = fps_tk1024(__float_as_uint(c4.w));
                     }
                     const bool take = kg < key;
@@ -1195,6 +1387,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         if (t == 0) picked[r] = wk;
         c3 = c3 == 2 ? 0 : c3 + 1;
     }
+    }   // single-sample rounds
     __syncthreads();
     for (int i = t; i < m; i += WGS) idx[i] = picked[i];
 }
@@ -1313,12 +1506,13 @@ static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int
     float *stdv = reinterpret_cast<float *>(rest);
     uint32_t *sidx = reinterpret_cast<uint32_t *>(rest + (size_t)b * np * 4);
     uint16_t *cells = reinterpret_cast<uint16_t *>(rest + (size_t)b * np * 8);
-    if (np == 32768)
-        hipLaunchKernelGGL((fps_paged_kernel<8>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream,
-                           n, c, m, clouds, idx, spts, stdv, sidx, cells, group_box);
-    else
-        hipLaunchKernelGGL((fps_paged_kernel<16>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream,
-                           n, c, m, clouds, idx, spts, stdv, sidx, cells, group_box);
+    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
+#define FPS_PAGED(NG_, MODE_)                                                                                         \
+    hipLaunchKernelGGL((fps_paged_kernel<NG_, MODE_>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, \
+                       m, clouds, idx, spts, stdv, sidx, cells, group_box)
+    if (np == 32768) { if (mode) FPS_PAGED(8, 1); else FPS_PAGED(8, 0); }
+    else             { if (mode) FPS_PAGED(16, 1); else FPS_PAGED(16, 0); }
+#undef FPS_PAGED
     return dclr_launch_status();
 }
 

@@ -34,6 +34,9 @@ def _cloud(kind, b, n, seed):
     ('normal', 1, 20000, 200), ('kitti', 1, 65536, 150), ('grid', 1, 40000, 100),
     ('normal', 2, 1025, 300), ('dup', 2, 2049, 400), ('grid', 3, 16383, 600), ('kitti', 2, 8193, 1100),
     ('grid', 2, 9000, 9000),
+    # a last group of one or two points that is not the first group of its wave (its box lane holds no point)
+    ('kitti', 2, 1089, 64), ('kitti', 2, 2113, 64), ('kitti', 2, 4225, 64), ('kitti', 2, 8449, 64), ('kitti', 2, 8192 + 512 + 2, 64),
+    ('normal', 2, 12288 + 768 + 1, 64),
 ])
 def test_fps_bit_exact(kind, b, n, m):
     xyz = _cloud(kind, b, n, seed=n + m)
@@ -115,6 +118,7 @@ def test_ops_reject_cpu_tensors_and_bad_sizes():
 @pytest.mark.parametrize('kind,b,n,m', [
     ('kitti', 2, 65536, 1024), ('normal', 2, 20000, 300), ('grid', 2, 40000, 500), ('dup', 2, 32768, 400),
     ('kitti', 1, 16385, 200), ('normal', 1, 32769, 257), ('grid', 1, 65535, 64),
+    ('kitti', 1, 16386, 60), ('kitti', 1, 16384 + 256 + 1, 60), ('kitti', 1, 32768 + 512 + 3, 60),   # tiny last group
 ])
 def test_fps_large_clouds_workspace_kernel_bit_exact(kind, b, n, m):
     """16384 < n <= 65536: the spatially pruned kernel with its points in a workspace (ops.fps_clouds) against
