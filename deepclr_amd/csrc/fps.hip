@@ -737,6 +737,21 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #endif
         }
         if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
+        if (temp) {
+            // level-1 contract: temp ends as the running minima over the first m - 1 samples. The last round's accepted
+            // samples are still pending: apply all but the final one (no pruning needed, this runs once).
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                if (j + 1 >= np) break;
+#pragma unroll
+                for (int jj = 0; jj < P; ++jj) {
+                    const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), pcx[j], pcy[j], pcz[j]);
+                    float d2;
+                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                    vec_set<P>(td, jj, d2);
+                }
+            }
+        }
 #ifdef FPS_DEBUG
         if (lane == 0 && blockIdx.x == 0) { fps_dbg[11] = (unsigned long long)sr; if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = ms; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; } }
 #endif
@@ -979,7 +994,8 @@ template <int NG, int MODE>                       // MODE as in fps_pruned_kerne
 __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int m, const float *__restrict__ pts,
                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
                                                          float *__restrict__ std_all, uint32_t *__restrict__ sidx_all,
-                                                         uint16_t *__restrict__ cell_all, float *__restrict__ group_box) {
+                                                         uint16_t *__restrict__ cell_all, float *__restrict__ group_box,
+                                                         float *__restrict__ temp) {
     constexpr int WGS = 1024, NW = 16, P = 4 * NG, NP = WGS * P, BINS = 4096;
     typedef typename VecOf<NG>::type gvec;
     __shared__ unsigned long long cell[3];
@@ -1001,6 +1017,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     uint32_t *sidx = sidx_all + (size_t)blockIdx.x * NP;
     uint16_t *cellof = cell_all + (size_t)blockIdx.x * NP;
     if (group_box) group_box += (size_t)blockIdx.x * NW * NG * 8;
+    if (temp) temp += (size_t)blockIdx.x * n;
 
     // ---- 1. bounding box ------------------------------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -1116,7 +1133,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 x = pts[(size_t)k * pstride + 0];
                 y = pts[(size_t)k * pstride + 1];
                 z = pts[(size_t)k * pstride + 2];
-                d = 1e10f;
+                d = temp ? temp[k] : 1e10f;
                 blo[0] = fminf(blo[0], x); blo[1] = fminf(blo[1], y); blo[2] = fminf(blo[2], z);
                 bhi[0] = fmaxf(bhi[0], x); bhi[1] = fmaxf(bhi[1], y); bhi[2] = fmaxf(bhi[2], z);
                 any = true;
@@ -1184,6 +1201,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                     float o[B][4];
 #pragma unroll
                     for (int u = 0; u < B; ++u) {
+                        if (!live[u]) break;                              // wave-uniform
                         const int base = (gs[u] * NW + wave) * 256 + lane;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { q[u][i] = spts[base + 64 * i]; o[u][i] = std_[base + 64 * i]; }
@@ -1275,6 +1293,24 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             sr += 1;
         }
         if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
+        if (temp) {                                            // pending samples except the final one (see fps_pruned_kernel)
+#pragma unroll 1
+            for (int g = 0; g < NG; ++g) {
+                const int base = (g * NW + wave) * 256 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 q = spts[base + 64 * i];
+                    float o = std_[base + 64 * i];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        if (j + 1 >= np) break;
+                        const float d = dclr_sqdist(q.x, q.y, q.z, pcx[j], pcy[j], pcz[j]);
+                        asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(d), "v"(o));
+                    }
+                    std_[base + 64 * i] = o;
+                }
+            }
+        }
     } else {
     float cx = pts[0], cy = pts[1], cz = pts[2];
     if (t == 0) picked[0] = 0;
@@ -1390,6 +1426,17 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     }   // single-sample rounds
     __syncthreads();
     for (int i = t; i < m; i += WGS) idx[i] = picked[i];
+    if (temp) {                                                // level-1 contract: the running minima go back to temp
+#pragma unroll 1
+        for (int g = 0; g < NG; ++g) {
+            const int base = (g * NW + wave) * 256 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t k = __float_as_uint(spts[base + 64 * i].w);
+                if (k != 0xFFFFFFFFu) temp[k] = std_[base + 64 * i];
+            }
+        }
+    }
 }
 
 int fps_block(int n) {
@@ -1472,12 +1519,6 @@ int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp
 
 }  // namespace
 
-extern "C" int dclr_furthest_point_sampling(int b, int n, int m, const float *points, float *temp,
-                                            int32_t *idx, dclr_stream_t stream) {
-    DCLR_REQUIRE(temp != nullptr);
-    return fps_dispatch(b, n, 3, m, points, temp, idx, (hipStream_t)stream);
-}
-
 extern "C" int dclr_fps_clouds(int b, int n, int c, int m, const float *clouds, int32_t *idx,
                                dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3);
@@ -1500,7 +1541,7 @@ extern "C" long long dclr_fps_workspace_bytes(int b, int n) {
 // Workspace sampler (16384 < n <= 65536). `spts` = the sorted points (float4 x, y, z, index bits; 1024 * P per cloud): a
 // slice of the workspace, or the caller's group_pts buffer when the groups are exported for set abstraction.
 static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int32_t *idx, float4 *spts, char *rest,
-                            float *group_box, hipStream_t stream) {
+                            float *group_box, float *temp, hipStream_t stream) {
     if ((size_t)m * sizeof(int32_t) > 32 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] shares LDS with the histogram
     const size_t np = n <= 32768 ? 32768 : 65536;
     float *stdv = reinterpret_cast<float *>(rest);
@@ -1509,11 +1550,33 @@ static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int
     static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
 #define FPS_PAGED(NG_, MODE_)                                                                                         \
     hipLaunchKernelGGL((fps_paged_kernel<NG_, MODE_>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, \
-                       m, clouds, idx, spts, stdv, sidx, cells, group_box)
+                       m, clouds, idx, spts, stdv, sidx, cells, group_box, temp)
     if (np == 32768) { if (mode) FPS_PAGED(8, 1); else FPS_PAGED(8, 0); }
     else             { if (mode) FPS_PAGED(16, 1); else FPS_PAGED(16, 0); }
 #undef FPS_PAGED
     return dclr_launch_status();
+}
+
+// Level 1 (the reference wrapper's signature has no workspace argument): clouds of 16385..65536 points take the
+// workspace kernel with a stream-ordered scratch allocation (hipMallocAsync / hipFreeAsync on the caller's stream).
+extern "C" int dclr_furthest_point_sampling(int b, int n, int m, const float *points, float *temp,
+                                            int32_t *idx, dclr_stream_t stream) {
+    DCLR_REQUIRE(temp != nullptr);
+    const size_t need = (b > 0 && n > 0) ? fps_ws_bytes_per_cloud(n) * (size_t)b : 0;
+    if (need == 0 || (size_t)m * sizeof(int32_t) > 32 * 1024 || getenv("DCLR_FPS_PLAIN"))
+        return fps_dispatch(b, n, 3, m, points, temp, idx, (hipStream_t)stream);
+    DCLR_REQUIRE(m > 0 && points && idx);
+    void *ws = nullptr;
+    if (hipMallocAsync(&ws, need, (hipStream_t)stream) != hipSuccess || ws == nullptr) {
+        (void)hipGetLastError();
+        return fps_dispatch(b, n, 3, m, points, temp, idx, (hipStream_t)stream);   // no scratch: the global-temp kernel
+    }
+    const size_t np = n <= 32768 ? 32768 : 65536;
+    char *w = static_cast<char *>(ws);
+    const int rc = fps_launch_paged(b, n, 3, m, points, idx, reinterpret_cast<float4 *>(w), w + (size_t)b * np * 16, nullptr,
+                                    temp, (hipStream_t)stream);
+    const hipError_t fe = hipFreeAsync(ws, (hipStream_t)stream);
+    return rc != DCLR_OK ? rc : fe == hipSuccess ? DCLR_OK : -(1000 + (int)fe);
 }
 
 extern "C" int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *clouds, int32_t *idx, void *workspace,
@@ -1525,7 +1588,7 @@ extern "C" int dclr_fps_clouds_ws(int b, int n, int c, int m, const float *cloud
     const size_t np = n <= 32768 ? 32768 : 65536;
     char *w = static_cast<char *>(workspace);
     return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(w), w + (size_t)b * np * 16, nullptr,
-                            (hipStream_t)stream);
+                            nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dclr_fps_group_layout(int n, int *n_groups, int *group_size) {
@@ -1542,7 +1605,7 @@ extern "C" int dclr_fps_clouds_grouped_ws(int b, int n, int c, int m, const floa
     const size_t np = n <= 32768 ? 32768 : 65536;
     DCLR_REQUIRE(workspace && workspace_bytes >= (long long)((size_t)b * np * 10) && ((uintptr_t)workspace & 15) == 0);
     return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(group_pts), static_cast<char *>(workspace),
-                            group_box, (hipStream_t)stream);
+                            group_box, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *clouds, int32_t *idx,

@@ -46,8 +46,10 @@ const char *dclr_error_string(int code);        /* static string, never NULL */
 /* Replaces furthest_point_sampling_wrapper(b, n, m, points, temp, idx)
  * (/root/reference/extern/pointnet2.patch:306-320).
  * points (b,n,3) f32; temp (b,n) f32 pre-filled by the caller (1e10); idx (b,m) i32.
- * idx[.,0] = 0; temp holds the final running minimum distances on return. Any n >= 1, m >= 1
- * (m > n keeps emitting index 0 once every point is taken). */
+ * idx[.,0] = 0; temp holds the final running minimum distances on return (over the first m - 1
+ * samples, as the reference's kernel leaves it). Any n >= 1, m >= 1 (m > n keeps emitting index 0
+ * once every point is taken). Clouds of 16385..65536 points run the workspace kernel on a scratch
+ * buffer allocated and freed in stream order (hipMallocAsync / hipFreeAsync on `stream`). */
 int dclr_furthest_point_sampling(int b, int n, int m, const float *points, float *temp,
                                  int32_t *idx, dclr_stream_t stream);
 

@@ -46,13 +46,15 @@ def test_fps_bit_exact(kind, b, n, m):
 
 
 def test_fps_level1_large_cloud_and_temp_side_effect():
-    """n > 65536 takes the global-temp kernel; temp must hold the final running minima."""
+    """Level 1 through the C symbol: n > 65536 takes the global-temp kernel, 16385..65536 the workspace kernel on a
+    stream-ordered scratch allocation, smaller clouds the register kernel; temp must hold the running minima over the
+    first m - 1 samples whichever kernel ran (several samples per round included)."""
     from deepclr_amd import lib
     xyz = _cloud('normal', 1, 70000, 5)
     m = 48
     want = oracle.furthest_point_sample(xyz, m)
     x = xyz.to(DEV)
-    for n_use in (70000, 3000):
+    for n_use in (70000, 40000, 20000, 16384, 3000):
         xs = x[:, :n_use].contiguous()
         temp = torch.full((1, n_use), 1e10, device=DEV)
         idx = torch.empty(1, m, dtype=torch.int32, device=DEV)
@@ -122,7 +124,7 @@ def test_ops_reject_cpu_tensors_and_bad_sizes():
 ])
 def test_fps_large_clouds_workspace_kernel_bit_exact(kind, b, n, m):
     """16384 < n <= 65536: the spatially pruned kernel with its points in a workspace (ops.fps_clouds) against
-    the oracle and against the level-1 entry point (global-temp kernel)."""
+    the oracle and against the level-1 entry point (same kernel on a stream-ordered scratch allocation)."""
     xyz = _cloud(kind, b, n, seed=n + m)
     want = oracle.furthest_point_sample(xyz, m)
     x = xyz.to(DEV)
