@@ -1,5 +1,10 @@
-"""Build libdeepclr_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libdeepclr_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every object is compiled with -Rpass-analysis=kernel-resource-usage; the remarks are condensed into
+csrc/<name>.usage.txt (kernel, VGPRs, scratch bytes, occupancy, LDS bytes). kernel_usage() reads them:
+tests/test_host.py keeps the hot kernels free of scratch (a spill in the sampler cost 20 % once)."""
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -28,6 +33,47 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+_REMARK = re.compile(r'remark: (?:Function Name: (?P<name>\S+)|\s+(?P<key>[A-Za-z ]+?)(?: \[[^\]]*\])?: (?P<val>\d+))')
+_KEYS = {'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'ScratchSize': 'scratch', 'Occupancy': 'occupancy', 'LDS Size': 'lds',
+         'SGPRs': 'sgprs'}
+
+
+def _write_usage(path: str, stderr: str) -> str:
+    """Condense the resource-usage remarks of one compile into `path`; returns the other diagnostics."""
+    rows, cur, rest = [], None, []
+    for line in stderr.splitlines():
+        if 'remark:' not in line or 'kernel-resource-usage' not in line:
+            if cur is None or line.strip() not in ('', '^'):
+                rest.append(line)
+            continue
+        m = _REMARK.search(line)
+        if not m:
+            continue
+        if m.group('name'):
+            cur = {'kernel': m.group('name')}
+            rows.append(cur)
+        elif cur is not None and m.group('key') in _KEYS:
+            cur[_KEYS[m.group('key')]] = int(m.group('val'))
+    with open(path, 'w') as f:
+        for r in rows:
+            f.write('{kernel} vgprs={vgprs} agprs={agprs} scratch={scratch} occupancy={occupancy} lds={lds}\n'.format(
+                **{k: r.get(k, 0) for k in ('kernel', 'vgprs', 'agprs', 'scratch', 'occupancy', 'lds')}))
+    return '\n'.join(l for l in rest if 'kernel-resource-usage' not in l and not l.startswith(' ') or 'error' in l or 'warning' in l)
+
+
+def kernel_usage() -> dict:
+    """{mangled kernel name: {'vgprs', 'agprs', 'scratch', 'occupancy', 'lds'}} from the last build's usage files."""
+    out = {}
+    for src in SOURCES:
+        path = os.path.join(CSRC, src.replace('.hip', '.usage.txt'))
+        if not os.path.exists(path):
+            continue
+        for line in open(path):
+            name, *fields = line.split()
+            out[name] = {k: int(v) for k, v in (f.split('=') for f in fields)}
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, h) for h in HEADERS]
@@ -44,8 +90,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
 
+    def compile_one(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        res = subprocess.run(cmd + ['-Rpass-analysis=kernel-resource-usage'], stderr=subprocess.PIPE, text=True)
+        rest = _write_usage(cmd[-1].replace('.o', '.usage.txt'), res.stderr)
+        if rest.strip():
+            sys.stderr.write(rest)
+        if res.returncode != 0:
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+
     with ThreadPoolExecutor(max_workers=4) as pool:
-        list(pool.map(run, jobs))
+        list(pool.map(compile_one, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
     return LIB

@@ -695,7 +695,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 int cnt = 0;
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    if (r + j >= m) break;                                    // uniform
+                    // level-1 contract: temp ends as the minima over the first m - 1 samples, so with temp the final
+                    // sample gets a round of its own (the samples accepted last are never applied)
+                    if (r + j >= m || (temp != nullptr && j > 0 && r + j == m - 1)) break;   // uniform
                     const uint32_t m_hi = dclr_row16_max_u32(e_hi);
                     // the wave holding it: unique unless two waves tie on the value (then the key field decides)
                     const uint32_t holders = (uint32_t)__ballot(e_hi == m_hi) & 0xFFFFu;
@@ -737,21 +739,6 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #endif
         }
         if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
-        if (temp) {
-            // level-1 contract: temp ends as the running minima over the first m - 1 samples. The last round's accepted
-            // samples are still pending: apply all but the final one (no pruning needed, this runs once).
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                if (j + 1 >= np) break;
-#pragma unroll
-                for (int jj = 0; jj < P; ++jj) {
-                    const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), pcx[j], pcy[j], pcz[j]);
-                    float d2;
-                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
-                    vec_set<P>(td, jj, d2);
-                }
-            }
-        }
 #ifdef FPS_DEBUG
         if (lane == 0 && blockIdx.x == 0) { fps_dbg[11] = (unsigned long long)sr; if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = ms; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; } }
 #endif
@@ -938,9 +925,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 // sqdist(p2, accepted) >= td[p2] and td[p2] exceeds the runner-up of every accepted sample's wave, and so on (<= J).
 // Writes picked[r..], plist[j] = coordinates, *plist_n = count.
 template <int J>
-__device__ __forceinline__ void fps_accept_samples(int par, int r, int m, int lane, unsigned long long (*wpk)[16],
-                                                   uint32_t (*wru)[16], FpsCand (*cand)[16], int32_t *picked,
-                                                   float (*plist)[4], int *plist_n) {
+__device__ __forceinline__ void fps_accept_samples(int par, int r, int m, bool last_alone, int lane,
+                                                   unsigned long long (*wpk)[16], uint32_t (*wru)[16], FpsCand (*cand)[16],
+                                                   int32_t *picked, float (*plist)[4], int *plist_n) {
     const unsigned long long e = wpk[par][lane & 15];
     const uint32_t e_ru = wru[par][lane & 15];
     const FpsCand w = cand[par][lane & 15];
@@ -950,7 +937,7 @@ __device__ __forceinline__ void fps_accept_samples(int par, int r, int m, int la
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        if (r + j >= m) break;                                    // uniform
+        if (r + j >= m || (last_alone && j > 0 && r + j == m - 1)) break;   // uniform; last_alone: see fps_pruned_kernel
         const uint32_t m_hi = dclr_row16_max_u32(e_hi);
         // the wave holding it: unique unless two waves tie on the value (then the key field decides)
         const uint32_t holders = (uint32_t)__ballot(e_hi == m_hi) & 0xFFFFu;
@@ -1284,7 +1271,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 wru[par][wave] = c_ru;
             }
             __syncthreads();
-            if (wave == 0) fps_accept_samples<J>(par, r, m, lane, wpk, wru, cand, picked, plist, &plist_n);
+            if (wave == 0) fps_accept_samples<J>(par, r, m, temp != nullptr, lane, wpk, wru, cand, picked, plist, &plist_n);
             __syncthreads();
             np = plist_n;
 #pragma unroll
@@ -1293,24 +1280,6 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             sr += 1;
         }
         if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
-        if (temp) {                                            // pending samples except the final one (see fps_pruned_kernel)
-#pragma unroll 1
-            for (int g = 0; g < NG; ++g) {
-                const int base = (g * NW + wave) * 256 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 q = spts[base + 64 * i];
-                    float o = std_[base + 64 * i];
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        if (j + 1 >= np) break;
-                        const float d = dclr_sqdist(q.x, q.y, q.z, pcx[j], pcy[j], pcz[j]);
-                        asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(d), "v"(o));
-                    }
-                    std_[base + 64 * i] = o;
-                }
-            }
-        }
     } else {
     float cx = pts[0], cy = pts[1], cz = pts[2];
     if (t == 0) picked[0] = 0;

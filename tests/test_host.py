@@ -250,3 +250,19 @@ def test_loss_values_match_reference_loss_modules():
         assert set(learned.get_weights()) == {'sx', 'sq'} and both.get_weights() == {}
     with pytest.raises(RuntimeError):
         losses.transform_losses(y_pred * float('nan'), y, lt, 2)
+
+
+def test_hot_kernels_do_not_spill():
+    """The build records every kernel's registers / scratch (deepclr_amd/build.py): nothing on the hot path may use
+    scratch memory -- the 16384-point sampler once picked up 196 bytes of it from an innocent-looking epilogue and ran
+    20 % slower. Allowed: the A/B and fallback kernels that the default path never launches."""
+    from deepclr_amd import build
+    usage = build.kernel_usage()
+    assert len(usage) >= 60, 'run python -m deepclr_amd.build'
+    allowed = ('fps_stream_kernel',)                                   # only reached without a workspace, or n > 65536
+    single_sample_ab = re.compile(r'fps_paged_kernelILi\d+ELi0E')     # DCLR_FPS_SINGLE=1
+    spilled = {k: v['scratch'] for k, v in usage.items()
+               if v['scratch'] and not any(a in k for a in allowed) and not single_sample_ab.search(k)}
+    assert not spilled, spilled
+    sampler = [v for k, v in usage.items() if 'fps_pruned_kernelILi1024ELi16ELi4ELi1E' in k]
+    assert sampler and sampler[0]['vgprs'] <= 128 and sampler[0]['occupancy'] >= 4      # 16 waves = one cloud per CU
