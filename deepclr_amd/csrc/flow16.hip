@@ -20,6 +20,13 @@ constexpr int F16_OUT = 256;
 constexpr int F16_STRIDE = dclr_split_stride(F16_C);    // 528 bytes per row
 constexpr int F16_KG = F16_C / 32;              // 4 k-steps of 32
 
+// Byte offset of k-octet o = 4 g + kq (hi 16 B, lo 16 B) inside an LDS row. NOT 32 o: ds_read_b128 is served in the lane
+// groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- rows 0-3 and 12-15 of one lane-quarter together with rows
+// 4-11 of the NEXT quarter -- so quarters kq and kq ^ 1 must sit a multiple of 256 B apart for the 16 lanes of a group
+// to cover 16 different 16-byte slots (row stride = 33 slots). With consecutive octets (32 B apart) every operand read
+// was 2-way conflicted: 5.2 M conflict cycles of 10.5 M LDS cycles (profiles/r01_e_pmc_split_fp16.txt).
+__host__ __device__ constexpr int f16_octet_offset(int o) { return 256 * (o & 1) + 128 * ((o >> 1) & 1) + 32 * (o >> 2); }
+
 // One pass over K for T row tiles x 2 channel tiles. TRANSPOSED: weights are the A operand.
 // ABL (timing-only ablations, results wrong): bit 0 = no gather round trips in phase A (rows built from constants),
 // bit 1 = weight fragments always from k-step 0 of tile 0 (no weight streaming), bit 2 = no phase A at all
@@ -35,7 +42,7 @@ __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4
     auto step = [&](int g, const dclr_h8 (&wh)[2], const dclr_h8 (&wl)[2]) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const char *p = a_lane + t * 16 * F16_STRIDE + 128 * g;
+            const char *p = a_lane + t * 16 * F16_STRIDE + 32 * g;
             const dclr_h8 ah = dclr_lds_h8(p), al = dclr_lds_h8(p + 16);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
         uint32_t bits = 0;
         int s_done = 0;
         // channels 2 lane, 2 lane + 1 sit in octet lane / 4 at half positions 2 (lane % 4), + 1
-        char *const slot = tile + 32 * (lane >> 2) + 4 * (lane & 3);
+        char *const slot = tile + f16_octet_offset(lane >> 2) + 4 * (lane & 3);
         if (live) {
             // Three dependent L2 round trips for the whole point instead of one or two per neighbour:
             // (1) the k neighbour indices, one per lane; (2) lane s fetches neighbour s's position, so the
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
     }
     __syncthreads();
 
-    const char *a_lane = tile + c16 * F16_STRIDE + 32 * kq;             // octet 4 g + kq of row c16 (+ tile offset)
+    const char *a_lane = tile + c16 * F16_STRIDE + f16_octet_offset(kq);   // octet 4 g + kq of row c16: + 32 g (+ tile offset)
 
     // ---- phase B: layer 2 (128 -> 128), wave w owns channel tiles 2w, 2w+1 ---------------------------
     {
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                                      fmaf(acc2[t][u][i + 1], DCLR_SPLIT_INV, acc[t][u][i + 1]), a, b);
                     hi[i] = a[0]; hi[i + 1] = a[1]; lo[i] = b[0]; lo[i + 1] = b[1];
                 }
-                char *dst = tile + (t * 16 + c16) * F16_STRIDE + 32 * (ch >> 3) + 2 * (ch & 7);
+                char *dst = tile + (t * 16 + c16) * F16_STRIDE + f16_octet_offset(ch >> 3) + 2 * (ch & 7);
                 *reinterpret_cast<dclr_h4 *>(dst) = hi;
                 *reinterpret_cast<dclr_h4 *>(dst + 16) = lo;
             }
