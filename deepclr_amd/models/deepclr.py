@@ -58,21 +58,31 @@ def _init_module(cfg: Config, *args: Any, **kwargs: Any) -> DeepCLRModule:
 # set abstraction
 # --------------------------------------------------------------------------------------------------
 class SetAbstraction(DeepCLRModule):
-    """Per-cloud feature extraction (reference: deepclr.py:48-94); one level (all shipped configs)."""
+    """Per-cloud feature extraction (reference: deepclr.py:48-94). Level 0 is the fused kernel; an optional second
+    level (deepclr.py:72-83,92-93; no shipped config has one) runs composed from the level-1 operators
+    (deepclr_amd/pointnet2.py) on the level-0 centroids and features."""
 
     def __init__(self, input_dim: int, point_dim: int, mlps: List[List[List[int]]], npoint: List[int],
                  radii: List[List[float]], nsamples: List[List[int]], batch_norm: bool = False, **_kwargs: Any):
         super().__init__()
         assert point_dim == 3
         assert len(mlps) == len(npoint) == len(radii) == len(nsamples)
-        if len(mlps) != 1:
-            raise NotImplementedError("a second set-abstraction level is not used by any shipped model")
+        assert 0 < len(mlps) <= 2
         feat_in = input_dim - point_dim
         self._input_dim = input_dim
         self._output_feat_dim = int(np.sum([spec[-1] for spec in mlps[-1]]))
         self._sa0 = PointnetSAModuleMSG(npoint=npoint[0], radii=radii[0], nsamples=nsamples[0],
                                         mlps=[[feat_in, *spec] for spec in mlps[0]], use_xyz=True, bn=batch_norm)
-        self.npoint = npoint[0]
+        if not self._sa0.fused:
+            raise NotImplementedError("level 0 must fit the fused kernel: xyz + <= 1 feature, mlp widths [16, 16, 32]")
+        if len(npoint) == 2:
+            self._sa1 = PointnetSAModuleMSG(npoint=npoint[1], radii=radii[1], nsamples=nsamples[1],
+                                            mlps=[[*spec] for spec in mlps[1]], use_xyz=True, bn=batch_norm)
+            if self._output_feat_dim > FEAT:
+                raise NotImplementedError("at most {} feature channels per point".format(FEAT))
+        else:
+            self._sa1 = None
+        self.npoint = npoint[-1]
 
     def output_dim(self) -> int:
         return 3 + self._output_feat_dim
@@ -82,7 +92,13 @@ class SetAbstraction(DeepCLRModule):
 
     def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
         """(2B, N, C) point-major clouds -> rows F."""
-        return self._sa0.forward_rows(clouds, sample)
+        rows = self._sa0.forward_rows(clouds, sample)
+        if self._sa1 is None:
+            return rows
+        b = clouds.shape[0]
+        ch = ops.rows_to_channels(rows, b, self._sa0.npoint, self._sa0.out_features())
+        xyz, feat = self._sa1(ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous())
+        return ops.channels_to_rows(torch.cat((xyz.transpose(1, 2), feat), dim=1).contiguous(), ops.F_STRIDE)
 
     def forward(self, clouds: torch.Tensor, *_args: Any) -> torch.Tensor:
         """(2B, C, N) channel-major clouds -> (2B, 3 + feat, npoint), as the reference module."""

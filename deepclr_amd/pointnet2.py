@@ -8,6 +8,14 @@ offers the same constructor and ``forward(xyz, features) -> (new_xyz, new_featur
 contract and the same parameter names (``mlps.{scale}.layer{j}.conv.{weight,bias}``,
 (out, in, 1, 1) weights, kaiming-normal init, zero bias) on top of the fused HIP
 set-abstraction kernel. The level-1 functions are re-exported under their upstream names.
+
+Two execution paths. The shape every shipped model uses for its first level -- xyz (+ <= 1 feature) in, shared MLP
+c -> 16 -> 16 -> 32 per scale -- runs in ONE fused kernel (csrc/sa.hip). Any other shape (a second level over 64
+feature channels, other MLP widths: reference deepclr.py:72-83) is composed from the level-1 HIP operators the
+reference itself composes (furthest_point_sample, gather_operation, ball_query, grouping_operation) plus the
+f32-MFMA ``dclr_linear`` for the shared MLP with the max over nsample folded into its last layer; torch only
+concatenates, pads and reshapes in between. That path is unfused and materialises the grouped tensor, as the
+reference does; it exists for coverage, not for speed.
 """
 from typing import List, Optional, Tuple
 
@@ -53,32 +61,46 @@ class PointnetSAModuleMSG(nn.Module):
                                       "(DeepCLR passes bn=batch_norm=False)")
         if not use_xyz or pool_method != 'max_pool':
             raise NotImplementedError("DeepCLR uses use_xyz=True with max pooling")
-        if not (len(radii) == len(nsamples) == len(mlps)) or not 1 <= len(radii) <= 2:
-            raise NotImplementedError("the fused kernel handles one or two grouping scales")
+        if not (len(radii) == len(nsamples) == len(mlps)) or len(radii) < 1:
+            raise ValueError("radii, nsamples and mlps must list the same (non-zero) number of scales")
         self.npoint = npoint
         self.radii = [float(r) for r in radii]
         self.nsamples = [int(s) for s in nsamples]
         self.mlps = nn.ModuleList()
         self._in_feat = None
+        self._out = []
+        fused = len(radii) <= 2
         for spec in mlps:
             spec = list(spec)
-            if spec[1:] != _FUSED_MLP:
-                raise NotImplementedError("the fused kernel is built for mlp widths {} (got {})"
-                                          .format(_FUSED_MLP, spec[1:]))
+            if len(spec) < 2 or (self._in_feat is not None and spec[0] != self._in_feat):
+                raise ValueError("every scale needs [in_features, width, ...] with the same in_features")
+            fused = fused and spec[1:] == _FUSED_MLP and spec[0] in (0, 1)
             self._in_feat = spec[0]
+            self._out.append(spec[-1])
             spec[0] += 3
             self.mlps.append(_SharedMLP(spec))
-        if self._in_feat not in (0, 1):
-            raise NotImplementedError("fused set abstraction takes xyz or xyz + 1 feature per point")
+        self.fused = fused                       # one-kernel path (csrc/sa.hip); otherwise level-1 operators + dclr_linear
         self._cache = PackedCache()
 
     def out_features(self) -> int:
-        return 32 * len(self.mlps)
+        return sum(self._out)
 
-    def packed_mlps(self) -> List[torch.Tensor]:
+    def packed_mlps(self):
+        """Fused path: one flat [W1 b1 W2 b2 W3 b3] buffer per scale. Composed path: per scale a list of
+        (packed weight, bias, n_out, padded K) for dclr_linear."""
         def build():
-            return [ops.pack_sa_mlp([u.conv.weight for u in stack], [u.conv.bias for u in stack])
-                    for stack in self.mlps]
+            if self.fused:
+                return [ops.pack_sa_mlp([u.conv.weight for u in stack], [u.conv.bias for u in stack])
+                        for stack in self.mlps]
+            packed = []
+            for stack in self.mlps:
+                layers = []
+                for u in stack:
+                    w = u.conv.weight.detach().reshape(u.conv.weight.shape[0], -1)
+                    kp = (w.shape[1] + 7) // 8 * 8
+                    layers.append((ops.pack_weight(w, kp), u.conv.bias.detach().contiguous(), w.shape[0], kp))
+                packed.append(layers)
+            return packed
         return self._cache.get(list(self.parameters()), build)
 
     def sample(self, clouds: torch.Tensor):
@@ -87,6 +109,8 @@ class PointnetSAModuleMSG(nn.Module):
         tensors are the sampling kernel's spatial partition, or None when it has none for this N."""
         if clouds.shape[2] != 3 + self._in_feat:
             raise RuntimeError("expected {} columns per point, got {}".format(3 + self._in_feat, clouds.shape[2]))
+        if not self.fused:
+            raise NotImplementedError("sample()/forward_rows() belong to the fused kernel; this module runs composed")
         return ops.fps_clouds_grouped(clouds, self.npoint)
 
     def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
@@ -102,8 +126,42 @@ class PointnetSAModuleMSG(nn.Module):
         """xyz (B, N, 3), features (B, C, N) or None -> new_xyz (B, npoint, 3), new_features (B, 32*scales, npoint)."""
         if new_xyz is not None:
             raise NotImplementedError("caller-supplied centroids are not used by DeepCLR")
+        if (0 if features is None else features.shape[1]) != self._in_feat:
+            raise RuntimeError("expected {} feature channels, got {}".format(
+                self._in_feat, 0 if features is None else features.shape[1]))
+        if not self.fused:
+            return self._forward_composed(xyz, features)
         clouds = xyz if features is None else torch.cat((xyz, features.transpose(1, 2)), dim=2)
         rows = self.forward_rows(clouds.contiguous())
         b = xyz.shape[0]
         ch = ops.rows_to_channels(rows, b, self.npoint, self.out_features())
         return ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous()
+
+    def _forward_composed(self, xyz: torch.Tensor, features: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The reference's own composition (QueryAndGroup + SharedMLP + max_pool2d) on the level-1 HIP operators."""
+        xyz = xyz.contiguous()
+        b = xyz.shape[0]
+        idx = ops.furthest_point_sample(xyz, self.npoint)
+        xyz_t = xyz.transpose(1, 2).contiguous()
+        new_xyz_t = ops.gather_operation(xyz_t, idx)                               # (B, 3, npoint)
+        new_xyz = new_xyz_t.transpose(1, 2).contiguous()
+        feats = None if features is None else features.contiguous()
+        outs = []
+        for radius, nsample, layers in zip(self.radii, self.nsamples, self.packed_mlps()):
+            bq = ops.ball_query(radius, nsample, xyz, new_xyz)                     # (B, npoint, nsample) int32
+            ns_p = (nsample + 63) // 64 * 64                                       # dclr_linear folds the max over blocks of 64 rows:
+            if ns_p != nsample:                                                    # pad with repeats of the first neighbour (max unchanged)
+                bq = torch.cat((bq, bq[:, :, :1].expand(-1, -1, ns_p - nsample)), dim=2).contiguous()
+            grouped = ops.grouping_operation(xyz_t, bq) - new_xyz_t.unsqueeze(-1)  # (B, 3, npoint, ns_p)
+            if feats is not None:
+                grouped = torch.cat((grouped, ops.grouping_operation(feats, bq)), dim=1)
+            c_in, kp0 = grouped.shape[1], layers[0][3]
+            rows = torch.zeros(b * self.npoint * ns_p, kp0, dtype=torch.float32, device=xyz.device)
+            rows[:, :c_in] = grouped.permute(0, 2, 3, 1).reshape(-1, c_in)
+            for j, (wp, bias, n_out, kp) in enumerate(layers):
+                if j + 1 < len(layers):
+                    rows = ops.linear(rows, wp, bias, n_out, kp, relu=True, ldy=layers[j + 1][3])
+                else:
+                    pooled = ops.linear(rows, wp, bias, n_out, kp, relu=True, colmax_groups=b * self.npoint)
+            outs.append(pooled.view(b, self.npoint, -1).transpose(1, 2))
+        return new_xyz, torch.cat(outs, dim=1).contiguous()

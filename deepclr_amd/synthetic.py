@@ -102,14 +102,15 @@ def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
     shapes: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
     sa = prm['cloud_features']['params']
     feat_in = cfg['input_dim'] - cfg['point_dim']
-    sa_out = 0
-    for s, spec in enumerate(sa['mlps'][0]):
-        chans = [feat_in + 3, *spec]
-        for j in range(len(spec)):
-            base = '_cloud_layers.0._sa0.mlps.{}.layer{}.conv'.format(s, j)
-            shapes[base + '.weight'] = (chans[j + 1], chans[j], 1, 1)
-            shapes[base + '.bias'] = (chans[j + 1],)
-        sa_out += spec[-1]
+    for lv in range(len(sa['mlps'])):            # level 1 specs start with their input width (deepclr.py:61 vs 73)
+        sa_out = 0
+        for s, spec in enumerate(sa['mlps'][lv]):
+            chans = [feat_in + 3, *spec] if lv == 0 else [spec[0] + 3, *spec[1:]]
+            for j in range(len(chans) - 1):
+                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}.conv'.format(lv, s, j)
+                shapes[base + '.weight'] = (chans[j + 1], chans[j], 1, 1)
+                shapes[base + '.bias'] = (chans[j + 1],)
+            sa_out += spec[-1]
     me = prm['merge']['params']
     chans = [3 + 2 * sa_out, *me['mlp']]
     for j in range(len(me['mlp'])):

@@ -104,11 +104,14 @@ class OracleDeepCLR:
         self.input_dim = int(model_cfg['input_dim'])
         self.point_dim = int(model_cfg['point_dim'])
         sa = prm['cloud_features']['params']
-        assert prm['cloud_features']['name'] == 'SetAbstraction' and len(sa['npoint']) == 1
-        self.npoint = int(sa['npoint'][0])
-        self.radii = [float(r) for r in sa['radii'][0]]
-        self.nsamples = [int(s) for s in sa['nsamples'][0]]
-        self.sa_layers = [len(m) for m in sa['mlps'][0]]
+        assert prm['cloud_features']['name'] == 'SetAbstraction' and 1 <= len(sa['npoint']) <= 2
+        # one entry per set-abstraction level (deepclr.py:63-83): level 1's mlp specs START with their input width,
+        # level 0's do not (deepclr.py:61 vs 73)
+        self.sa_levels = [{'npoint': int(sa['npoint'][lv]), 'radii': [float(r) for r in sa['radii'][lv]],
+                           'nsamples': [int(s) for s in sa['nsamples'][lv]],
+                           'layers': [len(m) - (1 if lv == 1 else 0) for m in sa['mlps'][lv]]}
+                          for lv in range(len(sa['npoint']))]
+        self.npoint = self.sa_levels[-1]['npoint']
         me = prm['merge']['params']
         assert prm['merge']['name'] == 'MotionEmbedding'
         self.k, self.radius = int(me['k']), float(me['radius'])
@@ -124,11 +127,12 @@ class OracleDeepCLR:
         x = x.to(torch.float32).transpose(1, 2)                        # (2B, C, N)
         xyz = x[:, :3, :].transpose(1, 2).contiguous()
         feats = x[:, 3:, :].contiguous() if x.size(1) > 3 else None
-        weights = [[(self.sd['_cloud_layers.0._sa0.mlps.{}.layer{}.conv.weight'.format(s, j)],
-                     self.sd['_cloud_layers.0._sa0.mlps.{}.layer{}.conv.bias'.format(s, j)])
-                    for j in range(n)] for s, n in enumerate(self.sa_layers)]
-        new_xyz, new_feat = sa_msg_forward(xyz, feats, self.npoint, self.radii, self.nsamples, weights)
-        return torch.cat((new_xyz.transpose(1, 2), new_feat), dim=1)   # (2B, 3+F, npoint)
+        for lv, level in enumerate(self.sa_levels):                    # deepclr.py:90-93
+            weights = [[(self.sd['_cloud_layers.0._sa{}.mlps.{}.layer{}.conv.weight'.format(lv, s, j)],
+                         self.sd['_cloud_layers.0._sa{}.mlps.{}.layer{}.conv.bias'.format(lv, s, j)])
+                        for j in range(n)] for s, n in enumerate(level['layers'])]
+            xyz, feats = sa_msg_forward(xyz, feats, level['npoint'], level['radii'], level['nsamples'], weights)
+        return torch.cat((xyz.transpose(1, 2), feats), dim=1)          # (2B, 3+F, npoint)
 
     # -- deepclr.py:142-173 ---------------------------------------------------------------------
     def knn_groups(self, cloud0: torch.Tensor, cloud1: torch.Tensor):

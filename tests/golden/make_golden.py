@@ -163,6 +163,16 @@ def small_global_cfg() -> dict:
     return cfg
 
 
+def small_two_level_cfg() -> dict:
+    """Two set-abstraction levels (reference: deepclr.py:72-83,92-93): 512 points -> 128 centroids x 64 features ->
+    64 centroids x (32 + 32) features."""
+    cfg = small_cfg()
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'] = [128, 64], [[2.0, 4.0], [4.0, 8.0]], [[8, 16], [8, 24]]
+    sa['mlps'] = [[[16, 16, 32], [16, 16, 32]], [[64, 32, 32], [64, 48, 32]]]
+    return cfg
+
+
 CASES = [
     # name,              cfg factory,                        batch factory,                              weight seed, full
     ('small_kitti_n512_b2', small_cfg, lambda: synthetic.make_batch('kitti', 2, 512), 11, True),
@@ -171,6 +181,7 @@ CASES = [
     ('modelnet_n1024_b1', lambda: synthetic.model_cfg('modelnet'),
      lambda: synthetic.make_batch('modelnet', 1, 1024), 14, False),
     ('small_global_n256_b2', small_global_cfg, lambda: synthetic.make_batch('kitti', 2, 256, first_pair=7), 15, True),
+    ('small_two_level_n512_b2', small_two_level_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=9), 16, True),
 ]
 
 
@@ -204,7 +215,14 @@ def run_case(ref, name, cfg, x_np, wseed, full):
     xyz = x[:, :, :3].contiguous()
     fps_idx = oracle.furthest_point_sample(xyz, sa['npoint'][0])
     new_xyz = oracle.gather_operation(xyz.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
-    assert torch.equal(new_xyz.transpose(1, 2), feat_ref[:, :3, :])
+    extra = {}
+    if len(sa['npoint']) == 1:
+        assert torch.equal(new_xyz.transpose(1, 2), feat_ref[:, :3, :])
+    else:                                        # second level samples the level-0 centroids (deepclr.py:92-93)
+        fps_idx1 = oracle.furthest_point_sample(new_xyz, sa['npoint'][1])
+        new_xyz1 = oracle.gather_operation(new_xyz.transpose(1, 2).contiguous(), fps_idx1)
+        assert torch.equal(new_xyz1, feat_ref[:, :3, :])
+        extra['fps_idx1'] = fps_idx1.numpy().astype(np.int16)
     bq = [oracle.ball_query(r, s, xyz, new_xyz) for r, s in zip(sa['radii'][0], sa['nsamples'][0])]
     half = feat_ref.shape[0] // 2
     npoint = feat_ref.shape[2]
@@ -219,7 +237,7 @@ def run_case(ref, name, cfg, x_np, wseed, full):
         'x': x_np, 'weight_seed': np.int64(wseed), 'fps_idx': fps_idx.numpy().astype(np.int16),
         'bq_sha256': np.array([_sha(t) for t in bq]),
         'knn_sha256': np.array(_sha(knn_local)),
-        'y': y_ref.numpy(), 'mat': mats_ref,
+        'y': y_ref.numpy(), 'mat': mats_ref, **extra,
     }
     if full:
         out.update(bq0=bq[0].numpy().astype(np.int16), bq1=bq[1].numpy().astype(np.int16),

@@ -16,6 +16,7 @@ GOLDEN_CASES = {
     'kitti_n2048_b1': ('kitti', False),
     'modelnet_n1024_b1': ('modelnet', False),
     'small_global_n256_b2': ('small_global', True),      # k == 0: GlobalGrouping
+    'small_two_level_n512_b2': ('small_two_level', True),   # second set-abstraction level (deepclr.py:72-83)
 }
 
 
@@ -34,10 +35,21 @@ def small_global_cfg() -> dict:
     return cfg
 
 
+def small_two_level_cfg() -> dict:
+    """Two set-abstraction levels: 512 points -> 128 centroids x 64 features -> 64 centroids x (32 + 32) features."""
+    cfg = small_cfg()
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'] = [128, 64], [[2.0, 4.0], [4.0, 8.0]], [[8, 16], [8, 24]]
+    sa['mlps'] = [[[16, 16, 32], [16, 16, 32]], [[64, 32, 32], [64, 48, 32]]]
+    return cfg
+
+
 def case_cfg(name: str) -> dict:
     kind = GOLDEN_CASES[name][0]
     if kind == 'small_global':
         return small_global_cfg()
+    if kind == 'small_two_level':
+        return small_two_level_cfg()
     return small_cfg() if kind == 'small' else synthetic.model_cfg(kind)
 
 

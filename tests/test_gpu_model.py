@@ -71,8 +71,11 @@ def test_model_matches_golden_and_oracle(name):
         y_feat, _, _ = model(feat, is_feat=True)
     assert loss is None and dbg is None
     # stage by stage against the reference-composition golden
+    picks = torch.from_numpy(g['fps_idx'].astype(np.int64))
+    if 'fps_idx1' in g.files:                     # second set-abstraction level: samples of the level-0 centroids
+        picks = picks.gather(1, torch.from_numpy(g['fps_idx1'].astype(np.int64)))
     assert torch.equal(feat[:, :3, :].cpu(), torch.from_numpy(g['x'])[:, :, :3].gather(
-        1, torch.from_numpy(g['fps_idx'].astype(np.int64))[:, :, None].expand(-1, -1, 3)).transpose(1, 2))
+        1, picks[:, :, None].expand(-1, -1, 3)).transpose(1, 2))
     if GOLDEN_CASES[name][1]:
         _close(feat, g['cloud_features'], stage=name + ': cloud_features vs reference golden')
         _close(emb, g['flow_embedding'], stage=name + ': flow_embedding vs reference golden')
@@ -230,6 +233,41 @@ def test_large_cloud_groups_from_the_workspace_sampler(n, pairs):
                                         want_counts=True, groups=(gpts, gbox))
     assert torch.equal(counts_a, counts_b) and torch.equal(rows_a, rows_b)
     assert int(counts_a.max()) > 1
+
+
+@pytest.mark.parametrize('feat, n, npoint, radii, nsamples, mlps', [
+    (64, 1024, 128, (0.3, 0.6), (16, 32), ([64, 64, 128], [64, 96, 128])),       # a PointNet++-style second level
+    (64, 300, 48, (0.25,), (24,), ([64, 32, 32],)),
+    (5, 2000, 100, (0.2, 0.4, 0.8), (8, 64, 100), ([5, 16], [5, 24, 24], [5, 8, 8, 40])),   # three scales, ragged depths
+    (0, 777, 33, (0.3,), (20,), ([0, 16, 16, 48],)),                             # xyz only, widths the fused kernel lacks
+])
+def test_composed_set_abstraction_against_oracle(feat, n, npoint, radii, nsamples, mlps):
+    """Shapes outside the fused kernel (feature inputs, other widths, three scales) run composed from the level-1 HIP
+    operators + dclr_linear with the max folded in (deepclr_amd/pointnet2.py): centroids exact, features within the
+    activation tolerance of the oracle's restatement of the same module."""
+    from deepclr_amd.pointnet2 import PointnetSAModuleMSG
+    from oracle.model import sa_msg_forward
+    rng = np.random.default_rng(n + feat)
+    pts = rng.normal(size=(2, n, 3))
+    pts /= np.linalg.norm(pts, axis=2, keepdims=True)
+    pts *= rng.uniform(0.2, 1.0, size=(2, n, 1))
+    xyz = torch.from_numpy(pts.astype(np.float32))
+    feats = torch.from_numpy(rng.normal(size=(2, feat, n)).astype(np.float32)) if feat else None
+    torch.manual_seed(3)
+    sam = PointnetSAModuleMSG(npoint=npoint, radii=list(radii), nsamples=list(nsamples), mlps=[list(m) for m in mlps],
+                              bn=False, use_xyz=True)
+    assert not sam.fused
+    for prm in sam.parameters():
+        if prm.dim() == 1:
+            torch.nn.init.uniform_(prm, -0.1, 0.1)
+    weights = [[(u.conv.weight.detach(), u.conv.bias.detach()) for u in stack] for stack in sam.mlps]
+    new_xyz_o, feat_o = sa_msg_forward(xyz, feats, npoint, list(radii), list(nsamples), weights)
+    sam = sam.to(DEV)
+    with torch.no_grad():
+        new_xyz, out = sam(xyz.to(DEV), None if feats is None else feats.to(DEV))
+    assert torch.equal(new_xyz.cpu(), new_xyz_o)
+    assert tuple(out.shape) == (2, sum(m[-1] for m in mlps), npoint)
+    _close(out, feat_o, stage='composed set abstraction (%d feature channels, %d scales) vs oracle' % (feat, len(radii)))
 
 
 def test_radius_mask_is_exercised():

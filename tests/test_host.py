@@ -82,6 +82,19 @@ def test_unsupported_configurations_fail_loudly():
     assert build_model(model_config_from_dict(cfg)) is not None
 
 
+def test_second_set_abstraction_level_builds_with_the_reference_key_layout():
+    """deepclr.py:72-83: a second level `_sa1` whose mlp specs start with their input width; its parameters sit under
+    `_cloud_layers.0._sa1.mlps.{scale}.layer{j}.conv.*` and load strictly."""
+    from helpers import small_two_level_cfg
+    cfg = small_two_level_cfg()
+    model = build_model(model_config_from_dict(cfg))
+    sd = synthetic.random_state_dict(cfg, seed=1)
+    assert sd['_cloud_layers.0._sa1.mlps.1.layer0.conv.weight'].shape == (48, 67, 1, 1)
+    model.load_state_dict(sd, strict=True)
+    sa = model._cloud_layers[0]
+    assert sa._sa0.fused and not sa._sa1.fused and sa.npoint == 64 and sa.output_dim() == 67
+
+
 def test_no_cpu_fallback():
     model = build_model(model_config_from_dict(synthetic.model_cfg('kitti')))
     with pytest.raises(RuntimeError):
