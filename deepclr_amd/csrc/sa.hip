@@ -152,7 +152,22 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
             h3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[1][j], h2[j], h3[1], 0, 0, 0);
         }
         const int cen = tag[16 * t + e16];
-        if (cen >= 0) {
+        const int cen0 = __builtin_amdgcn_readfirstlane(cen);
+        if (__ballot(cen != cen0) == 0) {
+            // The 16 entries of the tile (= one DPP row per lane quarter) belong to one centroid -- the common case, the
+            // ring is filled centroid by centroid: reduce over the row first and let one lane per quarter fold the
+            // result. Sixteen lanes hitting the same LDS word serialise: with dense neighbourhoods (ModelNet: ~45
+            // neighbours per centroid) the per-lane atomics were 3/4 of a drain (9.1 k of 12.5 k cycles).
+            if (cen0 >= 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t v = dclr_row16_max_lanes(__float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
+                        if (e16 == 15) atomicMax(acc + cen0 * SA_OUT + 16 * u + 4 * kq + i, v);
+                    }
+            }
+        } else if (cen >= 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll

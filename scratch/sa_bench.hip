@@ -7,14 +7,21 @@
 #include "../deepclr_amd/csrc/sa.hip"
 
 int main(int argc, char **argv) {
-    const int b = 16, n = 16384, m = 1024, c = 4;
     const bool use_groups = argc < 2 || atoi(argv[1]) != 0;
+    const bool modelnet = argc > 2 && atoi(argv[2]) != 0;          // 128 clouds of 2048 points on a sphere shell, c = 3
+    const int b = modelnet ? 128 : 16, n = modelnet ? 2048 : 16384, m = modelnet ? 512 : 1024, c = modelnet ? 3 : 4;
     std::mt19937 rng(1);
     std::normal_distribution<float> g(0.f, 1.f);
     std::uniform_real_distribution<float> u(-0.3f, 0.3f);
     std::vector<float> h((size_t)b * n * c);
     for (size_t i = 0; i < (size_t)b * n; ++i) {
-        h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
+        if (modelnet) {
+            float x = g(rng), y = g(rng), z = g(rng);
+            const float r = 0.75f / sqrtf(x * x + y * y + z * z + 1e-12f);
+            h[i * c + 0] = x * r + 0.02f * g(rng); h[i * c + 1] = y * r + 0.02f * g(rng); h[i * c + 2] = z * r + 0.02f * g(rng);
+        } else {
+            h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
+        }
     }
     std::vector<float> w(2 * 896);
     for (auto &v : w) v = u(rng);
@@ -25,7 +32,7 @@ int main(int argc, char **argv) {
     hipMemcpy(wd, w.data(), w.size() * 4, hipMemcpyHostToDevice);
     int rc = dclr_fps_clouds_grouped(b, n, c, m, d, idx, gp, gb, nullptr);
     hipDeviceSynchronize();
-    const float radii[2] = {0.5f, 1.0f}; const int ns[2] = {512, 1024};
+    const float radii[2] = {modelnet ? 0.1f : 0.5f, modelnet ? 0.2f : 1.0f}; const int ns[2] = {modelnet ? 256 : 512, modelnet ? 512 : 1024};
     const float *mlps[2] = {wd, wd + 896};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
