@@ -6,9 +6,9 @@
 // published torch-cluster 1.5.9 GPU kernel's strict-">" insertion list yields (oracle/primitives.c).
 //
 // A workgroup stages one candidate cloud in LDS; each wave then answers a few queries: lane l owns
-// candidates c*64 + l (CPL distance evaluations per lane) and the k nearest are extracted in k
-// rounds, each a two-step DPP reduction (min distance bits, then min index among equals) over
-// registers only.
+// candidates c*64 + l (CPL distance evaluations per lane); a ballot-counted threshold lets ~25-40 candidates
+// through, they are compacted to one per lane and ranked against each other; the general fallback extracts the
+// k nearest in k rounds of a two-step DPP reduction (min distance bits, then min index among equals).
 #include "common.h"
 
 namespace {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
         //     smallest lane minimum <= tau).
         //  2. all candidates <= tau are compacted (wave prefix sum, LDS) to one per lane -- typically 25-40 of
         //     the 1024; more than 64 (heavy ties) or no suitable pivot falls back to the general selection.
-        //  3. k rounds of wave arg-min over one register per lane (ties: lowest candidate index).
+        //  3. every survivor computes its rank among the survivors (ties: lowest candidate index) and the first k store.
         bool fast = false;
         {
             uint32_t lmin = d[0];
@@ -109,20 +109,21 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
                     for (int c = 0; c < CPL; ++c)
                         if (d[c] <= tau) { cd_lds[pos] = d[c]; ci_lds[pos] = (uint32_t)(c * 64 + lane); ++pos; }
                     // same wave wrote and reads: LDS operations of a wave complete in order
-                    uint32_t cd = lane < total ? cd_lds[lane] : 0xFFFFFFFFu;
+                    const uint32_t cd = lane < total ? cd_lds[lane] : 0xFFFFFFFFu;
                     const uint32_t ci = lane < total ? ci_lds[lane] : 0xFFFFFFFFu;
+                    // Selection by rank: a survivor's output slot is the number of survivors ordered before it
+                    // (distance, then candidate index) -- `total` steps of two lane reads and one 64-bit compare,
+                    // instead of k dependent wave arg-min rounds (~7 cross-lane steps each); every lane whose rank is
+                    // below k then stores its own result.
+                    const uint64_t key = ((uint64_t)cd << 32) | ci;
+                    int rank = 0;
 #pragma unroll 1
-                    for (int s = 0; s < k; ++s) {
-                        const uint32_t wmin = dclr_wave_min_u32(cd);
-                        const uint64_t holders = __ballot(cd == wmin);
-                        uint32_t widx;
-                        if (__builtin_popcountll(holders) == 1)
-                            widx = (uint32_t)__builtin_amdgcn_readlane((int)ci, __builtin_ctzll(holders));
-                        else
-                            widx = dclr_wave_min_u32(cd == wmin ? ci : 0xFFFFFFFFu);
-                        if (lane == 0) out(q, s, (int)widx);
-                        cd = ci == widx ? 0xFFFFFFFFu : cd;
+                    for (int j = 0; j < total; ++j) {
+                        const uint64_t kj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cd, j) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)ci, j);
+                        rank += kj < key ? 1 : 0;
                     }
+                    if (lane < total && rank < k) out(q, rank, (int)ci);
                     fast = true;
                 }
             }
