@@ -47,7 +47,7 @@ from deepclr_amd.pipeline import PipelinedForward, PipelinedSequence           #
 # pipelined runner (the sampler is one workgroup per cloud: c2 needs grouped launches to have enough clouds in
 # flight, c4 already brings 512 clouds per batch).
 CONFIGS = {
-    'c2': {'kind': 'kitti', 'pairs': 8, 'points': 16384, 'depth': 3, 'group': 4, 'dense_group': 1, 'steps': 200, 'warmup': 20,
+    'c2': {'kind': 'kitti', 'pairs': 8, 'points': 16384, 'depth': 3, 'group': 10, 'dense_group': 1, 'steps': 200, 'warmup': 20,
            'baseline': 'BASELINE.json configs[1]'},
     'c4': {'kind': 'modelnet', 'pairs': 256, 'points': 2048, 'depth': 2, 'group': 1, 'dense_group': 0, 'steps': 40, 'warmup': 5,
            'baseline': 'BASELINE.json configs[3]'},
@@ -324,7 +324,8 @@ def parse_args(argv=None):
     ap.add_argument('--dense-group', type=int, default=None, choices=[0, 1],
                     help='1: the dense stages (flow embedding, head, FC tail) of the batches sampled together also run '
                          'as one launch sequence over group x B pairs')
-    ap.add_argument('--gather-every', type=int, default=4, help='steps whose outputs share one all-gather (N > 1)')
+    ap.add_argument('--gather-every', type=int, default=None,
+                    help='steps whose outputs share one all-gather (N > 1); default: the dense group size, else 4')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group even for one rank (exercises the all-gather path on one GPU)')
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
@@ -407,6 +408,8 @@ def run(args):
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
+    if args.gather_every is None:            # one all-gather per dense group: its outputs are written in place
+        args.gather_every = args.group if getattr(runner, '_dense_group', False) else 4
     gather = OutputGather(dist, world, args.gather_every, pairs_per_step, model.label_dim, dev) if use_dist else None
     ranks_seen = [0]
     if use_dist:                             # proof that the collective spans `world` ranks

@@ -70,7 +70,8 @@ def test_peaks_and_workload_constants(bench):
     assert abs(bench.F16_MATRIX_PEAK_TFLOPS / bench.SPLIT_PRODUCTS - 838.9) < 0.1
     assert os.environ.get('GPU_MAX_HW_QUEUES') is not None                     # set on import, before HIP initialises
     args = bench.parse_args([])
-    assert (args.config, args.gpus, args.group, args.depth) == ('c2', 1, 4, 3) and args.steps >= 100
+    assert (args.config, args.gpus, args.group, args.depth) == ('c2', 1, 10, 3) and args.steps >= 100
+    assert 20 % args.group == 0                  # the driver's 20-step window holds whole sampling / dense groups
     args = bench.parse_args(['--config', 'c4', '--steps', '7'])
     assert (args.group, args.depth, args.steps) == (1, 2, 7)
 
