@@ -51,7 +51,7 @@ CONFIGS = {
            'baseline': 'BASELINE.json configs[1]'},
     'c4': {'kind': 'modelnet', 'pairs': 256, 'points': 2048, 'depth': 2, 'group': 1, 'dense_group': 0, 'steps': 40, 'warmup': 5,
            'baseline': 'BASELINE.json configs[3]'},
-    'c5': {'kind': 'kitti', 'pairs': 4, 'points': 65536, 'depth': 4, 'group': 8, 'dense_group': 1, 'steps': 200, 'warmup': 40,
+    'c5': {'kind': 'kitti', 'pairs': 4, 'points': 65536, 'depth': 2, 'group': 20, 'dense_group': 1, 'steps': 200, 'warmup': 40,
            'baseline': 'BASELINE.json configs[4]'},
 }
 PAIRS_PER_GPU = CONFIGS['c2']['pairs']
