@@ -133,11 +133,13 @@ def spawn_ranks(n: int, argv) -> int:
 # ----------------------------------------------------------------------------------------------------------
 class LaunchTimer:
     """HIP events around library launches, on the stream the kernel is enqueued on. Every SAMPLE_EVERY-th launch
-    of each kind is bracketed (the events themselves cost ~10 % when put around everything); counted per kind,
-    not per step, so that launches covering several batches (one sampling / dense launch per `group` steps) are
-    sampled at the same rate whatever the warm-up count."""
+    of each kind is bracketed; counted per kind, not per step, so that launches covering several batches (one
+    sampling / dense launch per `group` steps) are sampled at the same rate whatever the warm-up count. With ten
+    batches per launch there are < 1 spans per step and every launch is bracketed (the driver's 20-step window
+    holds two dense launches); when every batch had launches of its own the events cost ~10 % and every third
+    launch was sampled."""
 
-    SAMPLE_EVERY = 3
+    SAMPLE_EVERY = 1
 
     def __init__(self, sample_every=None):
         self.spans = []

@@ -85,10 +85,12 @@ def test_launch_timer_samples_per_kind_not_per_step(bench, monkeypatch):
         cuda_stream = 7
     monkeypatch.setattr(bench.torch.cuda, 'Event', _Ev)
     monkeypatch.setattr(bench.torch.cuda, 'current_stream', lambda: _S())
-    t = bench.LaunchTimer()
+    t = bench.LaunchTimer(sample_every=3)
     hits = [t.begin('fps_clouds[64x16384]') is not None for _ in range(9)]
     assert hits == [True, False, False] * 3 and t.calls['fps_clouds[64x16384]'] == 9
     assert t.begin('sa_msg_fused[64x16384]') is not None                      # kinds are counted separately
+    every = bench.LaunchTimer()                                               # default: every launch (few, grouped launches)
+    assert all(every.begin('fps_clouds[160x16384]') is not None for _ in range(4))
 
 
 def test_rank_environments_of_the_self_launcher(bench):
