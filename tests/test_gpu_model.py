@@ -197,14 +197,14 @@ def _check_set_abstraction(c, n, npoint, radii, nsamples, expect_cap=True):
         assert not expect_cap or (hits == ns).any() or r < 0.1
 
 
-@pytest.mark.parametrize('n, pairs', [(20000, 1), (32768, 1), (40000, 1), (65536, 2)])
-def test_large_cloud_groups_from_the_workspace_sampler(n, pairs):
+@pytest.mark.parametrize('n, pairs, c', [(20000, 1, 4), (32768, 1, 4), (40000, 1, 4), (65536, 2, 4), (50000, 1, 3), (17000, 1, 3)])
+def test_large_cloud_groups_from_the_workspace_sampler(n, pairs, c):
     """16384 < n <= 65536: the workspace sampler exports its 128 / 256 groups of 256 points and set abstraction takes
     the grouped fast path over them: same samples as the ungrouped call, groups = a permutation of the cloud with
     tight boxes, rows and counts bit-identical to the exhaustive sweep."""
     cfg = synthetic.model_cfg('kitti')
     sa = {k_: v[0] for k_, v in cfg['params']['cloud_features']['params'].items()}
-    x = torch.from_numpy(synthetic.make_batch('kitti', pairs, n, first_pair=41)).to(DEV)
+    x = torch.from_numpy(synthetic.make_batch('kitti', pairs, n, first_pair=41)[:, :, :c].copy()).to(DEV)
     npoint = int(sa['npoint'])
     idx, gpts, gbox = ops.fps_clouds_grouped(x, npoint)
     assert gpts is not None and ops.fps_group_layout(n) == ((128 if n <= 32768 else 256), 256)
@@ -227,7 +227,7 @@ def test_large_cloud_groups_from_the_workspace_sampler(n, pairs):
     from deepclr_amd.pointnet2 import PointnetSAModuleMSG
     torch.manual_seed(9)
     sam = PointnetSAModuleMSG(npoint=npoint, radii=list(sa['radii']), nsamples=list(sa['nsamples']),
-                              mlps=[[1, 16, 16, 32] for _ in sa['radii']], bn=False, use_xyz=True).to(DEV)
+                              mlps=[[c - 3, 16, 16, 32] for _ in sa['radii']], bn=False, use_xyz=True).to(DEV)
     rows_a, counts_a = ops.sa_msg_fused(x, idx, list(sa['radii']), list(sa['nsamples']), sam.packed_mlps(), want_counts=True)
     rows_b, counts_b = ops.sa_msg_fused(x, idx, list(sa['radii']), list(sa['nsamples']), sam.packed_mlps(),
                                         want_counts=True, groups=(gpts, gbox))
