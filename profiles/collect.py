@@ -31,8 +31,10 @@ KERNEL_TO_SPAN = [('fps_', 'fps_clouds'), ('sa_msg_kernel', 'sa_msg_fused'), ('k
                   ('flow16_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding'),
                   ('head16', 'head_conv_fused'), ('head_fused_kernel', 'head_conv_fused'),
                   ('linear_kernel', 'linear_pair'), ('fc_kernel', 'fc')]
-BENCH_ARGS = {'c2': ['--steps', '8', '--warmup', '2'], 'c4': ['--steps', '4', '--warmup', '1'],
-              'c5': ['--steps', '6', '--warmup', '2']}
+# enough steps for several grouped launches of every kind in steady state (c2: 10 batches per launch, c5: 20), so that
+# the per-kernel averages are those of the contended run bench.py's `avg_us` reports
+BENCH_ARGS = {'c2': ['--steps', '60', '--warmup', '20'], 'c4': ['--steps', '6', '--warmup', '2'],
+              'c5': ['--steps', '80', '--warmup', '40']}
 CALIB = os.path.join(ROOT, 'profiles', 'calib_copy.py')
 
 
