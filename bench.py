@@ -316,6 +316,8 @@ def parse_args(argv=None):
     ap.add_argument('--config', default='c2', choices=sorted(CONFIGS),
                     help='workload: c2 = BASELINE.json configs[1] (headline), c4 = configs[3], c5 = configs[4]')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--alone-only', type=int, default=0, metavar='N',
+                    help='no timed window: N passes of the launches one after another (for rocprofv3)')
     ap.add_argument('--no-launch-timer', action='store_true', help='skip per-kernel HIP events (roofline = null)')
     ap.add_argument('--no-overlap', action='store_true', help='run sampling in line instead of batches ahead')
     ap.add_argument('--depth', type=int, default=None, help='batches whose sampling runs ahead on side streams')
@@ -452,6 +454,50 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def solo_pass(iters):
+        """Untimed pass: the same launches one after another on one stream, so that each kernel's duration is its
+        own (in the timed region they share the CUs with the sampler running ahead). Returns (per-kernel summary,
+        mean barrier rounds of the sampler)."""
+        solo = LaunchTimer(sample_every=1)
+        ops.TIMER = solo
+        with torch.no_grad():
+            g = args.group if (args.group > 1 and not args.sequence and runner is not None) else 1
+            dense_g = g if getattr(runner, '_dense_group', False) else 1
+            half = x.shape[0] // 2
+            xs = torch.cat([x[:half]] * g + [x[half:]] * g) if dense_g > 1 else torch.cat([x] * g)
+            for _ in range(iters):
+                if args.sequence:
+                    f_rows = model.cloud_feature_rows(x)
+                    rows, pairs, _ = model.sequence_rows(f_rows, x.shape[0], f_rows[-model.npoint:])
+                    model.merge_rows(rows, pairs)
+                else:
+                    # the same launch sizes as the timed region: sampling stages over group x 2B clouds, the dense
+                    # stages over the batches of one dense launch
+                    f_all = model.cloud_feature_rows(xs)
+                    if dense_g > 1:
+                        model.merge_rows(f_all, half * g)
+                    else:
+                        model.merge_rows(f_all[:x.shape[0] * model.npoint], half)
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        rounds = None
+        if not args.sequence:
+            with torch.no_grad():
+                sample = model.sample(xs)                      # (idx, group_pts, group_box): box[:, 0, 6] = barrier rounds
+            if sample[2] is not None:
+                rounds = float(sample[2][:, 0, 6].mean())
+        return solo.summary(), rounds
+
+    if args.alone_only:
+        # profiling aid (profiles/collect.py): no timed window, only the launches one after another at the launch
+        # sizes of the pipelined run -- a rocprofv3 kernel-stats summary of this command backs `alone_us`
+        summary, rounds = solo_pass(args.alone_only)
+        if rank == 0:
+            print(json.dumps({'alone_pass': True, 'config': args.config, 'iterations': args.alone_only,
+                              'kernels_alone_us': {k: round(v['avg_us'], 1) for k, v in summary.items()},
+                              'fps_rounds': rounds}))
+        return
+
     for _ in range(args.warmup):
         y = step()
     timer = None if args.no_launch_timer else LaunchTimer()
@@ -467,37 +513,7 @@ def run(args):
     ops.TIMER = None
     alone, fps_rounds = None, None
     if timer is not None and rank == 0:
-        # second, untimed pass: the same launches one after another on one stream, so that each kernel's
-        # duration is its own (in the timed region they share the CUs with the sampler running ahead)
-        solo = LaunchTimer(sample_every=1)
-        ops.TIMER = solo
-        with torch.no_grad():
-            g = args.group if (args.group > 1 and not args.sequence and runner is not None) else 1
-            dense_g = g if getattr(runner, '_dense_group', False) else 1
-            half = x.shape[0] // 2
-            xs = torch.cat([x[:half]] * g + [x[half:]] * g) if dense_g > 1 else torch.cat([x] * g)
-            for _ in range(6):
-                if args.sequence:
-                    f_rows = model.cloud_feature_rows(x)
-                    rows, pairs, _ = model.sequence_rows(f_rows, x.shape[0], f_rows[-model.npoint:])
-                    model.merge_rows(rows, pairs)
-                else:
-                    # the same launch sizes as the timed region: sampling stages over group x 2B clouds, the dense
-                    # stages over the batches of one dense launch
-                    f_all = model.cloud_feature_rows(xs)
-                    if dense_g > 1:
-                        model.merge_rows(f_all, half * g)
-                    else:
-                        model.merge_rows(f_all[:x.shape[0] * model.npoint], half)
-        torch.cuda.synchronize()
-        ops.TIMER = None
-        alone = solo.summary()
-        fps_rounds = None
-        if not args.sequence:
-            with torch.no_grad():
-                sample = model.sample(xs)                      # (idx, group_pts, group_box): box[:, 0, 6] = barrier rounds
-            if sample[2] is not None:
-                fps_rounds = float(sample[2][:, 0, 6].mean())
+        alone, fps_rounds = solo_pass(6)
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -130,6 +130,12 @@ def main():
                 os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, cfg)))
             for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
                 shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, cfg)))
+            # the launches one after another, nothing else on the chip: backs bench.py's `alone_us` / `frac_alone`
+            d = os.path.join(out, 'raw_alone_' + cfg)
+            run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', py, 'bench.py', '--config', cfg,
+                 '--alone-only', '6'], os.path.join(out, '{}_{}_alone_under_rocprof.log'.format(args.tag, cfg)))
+            for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+                shutil.copy(path, os.path.join(out, '{}_{}_alone_kernel_stats.csv'.format(args.tag, cfg)))
         if args.skip_pmc:
             continue
         spans = {}
