@@ -59,11 +59,27 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
         float qx, qy, qz;
         query.load(query_cloud, ny, q, qx, qy, qz);          // wave-uniform
         uint32_t d[CPL];
+        if constexpr (CPL % 2 == 0) {
+            // two candidates per instruction (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations in the same order
+            // as dclr_sqdist -- (candidate - query), accumulated x, y, z: the published kernel's order)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-            const int i = c * 64 + lane;
-            // (candidate - query), accumulated x,y,z: the published kernel's order
-            d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
+            for (int c = 0; c < CPL; c += 2) {
+                const int i = c * 64 + lane;
+                const f2 ax = {sx[i], sx[i + 64]}, ay = {sy[i], sy[i + 64]}, az = {sz[i], sz[i + 64]};
+                const f2 dx = ax - q2x, dy = ay - q2y, dz = az - q2z;
+                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const f2 dd = (xx + yy) + zz;
+                d[c] = i < nx ? __float_as_uint(dd[0]) : KNN_INF;
+                d[c + 1] = i + 64 < nx ? __float_as_uint(dd[1]) : KNN_INF;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int i = c * 64 + lane;
+                d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
+            }
         }
         // Fast path: shrink the problem to <= 64 candidates, one per lane, then run the k arg-min rounds on those.
         //  1. threshold: a value tau with k <= #lanes(lane minimum <= tau) <= KNN_LIMIT, found by a few pivot
@@ -92,22 +108,21 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
                 else { tau = piv; found = true; }
             }
             if (found && tau < KNN_INF) {
-                int cnt = 0;
+                // count and compact in one pass: a ballot per candidate slice gives the slice's survivors their places
+                // (most slices of a lane's 16 hold none); the order of the survivors is irrelevant, they are ranked below
+                uint32_t *cd_lds = knn_compact + wave * 128, *ci_lds = cd_lds + 64;
+                int total = 0;
 #pragma unroll
-                for (int c = 0; c < CPL; ++c) cnt += d[c] <= tau ? 1 : 0;
-                int incl = cnt;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int up = __shfl_up(incl, off);
-                    if (lane >= off) incl += up;
+                for (int c = 0; c < CPL; ++c) {
+                    const bool pass = d[c] <= tau;
+                    const uint64_t mask = __ballot(pass);
+                    if (mask != 0) {                                 // wave-uniform
+                        const int pos = total + (int)dclr_lanemask_lt_popc(mask);
+                        if (pass && pos < 64) { cd_lds[pos] = d[c]; ci_lds[pos] = (uint32_t)(c * 64 + lane); }
+                        total += __builtin_popcountll(mask);
+                    }
                 }
-                const int total = __builtin_amdgcn_readlane(incl, 63);
                 if (total <= 64) {                                   // wave-uniform
-                    uint32_t *cd_lds = knn_compact + wave * 128, *ci_lds = cd_lds + 64;
-                    int pos = incl - cnt;
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-                        if (d[c] <= tau) { cd_lds[pos] = d[c]; ci_lds[pos] = (uint32_t)(c * 64 + lane); ++pos; }
                     // same wave wrote and reads: LDS operations of a wave complete in order
                     const uint32_t cd = lane < total ? cd_lds[lane] : 0xFFFFFFFFu;
                     const uint32_t ci = lane < total ? ci_lds[lane] : 0xFFFFFFFFu;
