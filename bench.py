@@ -407,7 +407,8 @@ def run(args):
     else:
         dense_group = bool(args.dense_group) and args.ahead == 'knn' and args.group > 1
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
-                                                               group=args.group, dense_group=dense_group)
+                                                               group=args.group, dense_group=dense_group,
+                                                               inputs_ready=True)   # the batch is resident and never rewritten
     if runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)

@@ -17,7 +17,7 @@ from .models.deepclr import DeepCLR
 
 class PipelinedForward:
     def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
-                 dense_group: bool = False):
+                 dense_group: bool = False, inputs_ready: bool = False):
         """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
         abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
         the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
@@ -31,7 +31,12 @@ class PipelinedForward:
         dense_group (needs ahead='knn'): the dense stages of the `group` batches sampled together also run as ONE
         launch sequence (flow embedding, head and fully connected tail over group x B pairs, enqueued when the
         first batch of the group is stepped): a single batch of 8 KITTI pairs is 8192 head rows = 128 workgroups,
-        half the chip, and three ~13 us fully connected launches per batch were a fifth of the main stream."""
+        half the chip, and three ~13 us fully connected launches per batch were a fifth of the main stream.
+        inputs_ready: the batches handed in are complete in memory and stay untouched until their results are out
+        (resident data, or produced on another stream and already synchronised). By default a sampling launch waits
+        for everything enqueued on the caller's stream so far -- the safe assumption that the batch was produced
+        there -- which also orders it behind the dense launches of OLDER batches the runner itself put on that
+        stream; with inputs_ready it starts at once."""
         if dense_group and (ahead != 'knn' or group < 2):
             raise ValueError("dense_group needs ahead='knn' and group > 1")
         if depth < 1:
@@ -46,6 +51,9 @@ class PipelinedForward:
         self.group = group
         self._ahead = ahead
         self._dense_group = dense_group
+        self._inputs_ready = inputs_ready
+        self._hold_launch = False                   # dense groups: a full sampling group is launched right AFTER the next
+                                                    # dense launch has been enqueued (the host needs ~0.3 ms for the chain)
         self._group_out = None                      # (batches of the running dense group, their outputs)
         self._waiting = []                          # batches collected for the next grouped launch
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
@@ -56,7 +64,7 @@ class PipelinedForward:
         """Start sampling for `x` (2B, N, C) on the next side stream (with group > 1: once `group` batches have
         been handed in, or at once if flush)."""
         self._waiting.append(x)
-        if len(self._waiting) >= self.group or flush:
+        if flush or (len(self._waiting) >= self.group and not self._hold_launch):
             self._launch()
 
     def _launch(self) -> None:
@@ -67,7 +75,8 @@ class PipelinedForward:
         main = torch.cuda.current_stream()
         side = self._streams[self._next_stream]
         self._next_stream = (self._next_stream + 1) % self.depth
-        side.wait_stream(main)                               # the batches (and anything producing them) are ready
+        if not self._inputs_ready:
+            side.wait_stream(main)                           # the batches (and anything producing them) are ready
         with torch.cuda.stream(side), torch.no_grad():
             if len(xs) == 1:
                 out = self._model.sample(xs[0])
@@ -129,10 +138,12 @@ class PipelinedForward:
             batches, y_all = self._group_out
             pos = y_all.shape[0] // (x.shape[0] // 2) - len(batches)
             batches.pop(0)
+            self._hold_launch = True
             for nxt in upcoming:
                 if self.in_flight() >= self.depth * self.group:
                     break
                 self.prefetch(nxt, flush=False)
+            self._hold_launch = False
             y = y_all[pos * (x.shape[0] // 2):(pos + 1) * (x.shape[0] // 2)]
             return y if out is None else out.copy_(y)
         if not self._pending and self._waiting and self._waiting[0] is x:
@@ -142,10 +153,6 @@ class PipelinedForward:
             main.wait_event(done)
             for t in self._tensors((rows, prep)):
                 t.record_stream(main)
-            for nxt in upcoming:
-                if self.in_flight() >= self.depth * self.group:
-                    break
-                self.prefetch(nxt, flush=False)
             pairs = x.shape[0] // 2
             want = len(xs) * pairs
             whole = out is not None and out.shape[0] == want
@@ -154,6 +161,14 @@ class PipelinedForward:
             if hasattr(prep, 'release'):
                 prep.release()                               # its buffers may be reused once these launches are through
             self._group_out = (list(xs[1:]), y_all)
+            # the dense stages are enqueued (one foreign call); now the sampling group held back during the slice steps
+            # and whatever else fits the pipeline depth
+            if len(self._waiting) >= self.group:
+                self._launch()
+            for nxt in upcoming:
+                if self.in_flight() >= self.depth * self.group:
+                    break
+                self.prefetch(nxt, flush=False)
             y = y_all[:pairs]
             return y if (out is None or whole) else out.copy_(y)
         if self._pending and self._pending[0][0] is x:
