@@ -141,6 +141,8 @@ class LaunchTimer:
 
     SAMPLE_EVERY = 1
 
+    POOL = 256                       # events created up front: creation is host time inside a short timed window
+
     def __init__(self, sample_every=None):
         self.spans = []
         self.raw = []
@@ -149,6 +151,14 @@ class LaunchTimer:
         self.main_stream = torch.cuda.current_stream().cuda_stream
         if sample_every is not None:
             self.SAMPLE_EVERY = sample_every
+        self._pool = []
+        try:
+            self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(self.POOL)]
+        except Exception:            # CPU-only unit tests patch torch.cuda.Event; a missing device must not matter here
+            self._pool = []
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def next_step(self):
         pass
@@ -161,14 +171,14 @@ class LaunchTimer:
     def begin(self, name):
         if not self._sampled(name):
             return None
-        start = torch.cuda.Event(enable_timing=True)
+        start = self._event()
         start.record()
         return (name, start, torch.cuda.current_stream().cuda_stream == self.main_stream)
 
     def end(self, token):
         if token is None:
             return
-        stop = torch.cuda.Event(enable_timing=True)
+        stop = self._event()
         stop.record()
         self.spans.append((token[0], token[1], stop, token[2]))
 
