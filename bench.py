@@ -15,6 +15,15 @@ exchange is an RCCL all-gather of the pose outputs.
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one fresh child process
 per GPU, before this process has touched the GPU) and relays rank 0's JSON line. Rank 0 prints ONE JSON line.
 The CPU oracle is used only for the `cpu_baseline` leg and the pose check -- never inside the timed region.
+
+Lines beside the headline (same schema, `config.mode` says which; profiles/r03_*):
+  --strict    one batch of B pairs per sampling launch and per dense launch (no cross-batch fusion)
+  --h2d       every step's batch is copied from pinned host memory inside the loop (copy stream, overlapped),
+              as the reference does per pair (/root/reference/scripts/inference.py:89-90)
+  --clouds ring   LiDAR-density clouds (64 rings x azimuth, deepclr_amd/synthetic.py:ring_scan): ball queries reach
+              their nsample caps, which the Gaussian clouds of the headline never do
+  --latency   the reference's own call pattern: one pair per ModelInferenceHelper.predict call, per-pair ms between
+              events as /root/reference/scripts/timing.py:32-47 takes it (pairwise and sequential)
 """
 import argparse
 import hashlib
@@ -41,7 +50,7 @@ from deepclr_amd import ops, synthetic                      # noqa: E402
 from deepclr_amd.config import model_config_from_dict       # noqa: E402
 from deepclr_amd.labels import LabelType                    # noqa: E402
 from deepclr_amd.models import build_model                  # noqa: E402
-from deepclr_amd.pipeline import PipelinedForward, PipelinedSequence           # noqa: E402
+from deepclr_amd.pipeline import HostBatchFeeder, PipelinedForward, PipelinedSequence           # noqa: E402
 
 # BASELINE.json configs that fit one GPU. depth / group: side streams and batches per sampling launch of the
 # pipelined runner (the sampler is one workgroup per cloud: c2 needs grouped launches to have enough clouds in
@@ -143,7 +152,10 @@ class LaunchTimer:
 
     POOL = 256                       # events created up front: creation is host time inside a short timed window
 
-    def __init__(self, sample_every=None):
+    RAW_POOL = 48                    # dclr_merge_forward calls bracketed before the pool has to grow inside the window
+
+    def __init__(self, sample_every=None, raw_pool=None):
+        raw_pool = self.RAW_POOL if raw_pool is None else raw_pool
         self.spans = []
         self.raw = []
         self.calls = {}
@@ -152,10 +164,48 @@ class LaunchTimer:
         if sample_every is not None:
             self.SAMPLE_EVERY = sample_every
         self._pool = []
+        self._raw_pool = []          # arrays of MERGE_EVENTS raw hipEvent_t, created here, destroyed by close()
+        self._raw_all = []
         try:
             self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(self.POOL)]
         except Exception:            # CPU-only unit tests patch torch.cuda.Event; a missing device must not matter here
             self._pool = []
+        if raw_pool and self._pool:
+            try:
+                self._hip = self._load_hip()
+            except OSError:
+                raw_pool = 0
+            for _ in range(raw_pool):
+                arr = self._new_raw()
+                if arr is None:
+                    break
+                self._raw_pool.append(arr)
+
+    @staticmethod
+    def _load_hip():
+        import ctypes
+        return ctypes.CDLL('libamdhip64.so')
+
+    def _new_raw(self):
+        import ctypes
+        from deepclr_amd import lib
+        arr = (ctypes.c_void_p * lib.MERGE_EVENTS)()
+        for i in range(lib.MERGE_EVENTS):
+            ev = ctypes.c_void_p()
+            if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
+                return None
+            arr[i] = ev.value
+        self._raw_all.append(arr)
+        return arr
+
+    def close(self):
+        """Destroy the raw events (after summary(): a 200-step run or a solo pass otherwise leaks ten handles per call)."""
+        import ctypes
+        for arr in self._raw_all:
+            for h in arr:
+                if h:
+                    self._hip.hipEventDestroy(ctypes.c_void_p(h))
+        self._raw_all, self._raw_pool, self.raw = [], [], []
 
     def _event(self):
         return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
@@ -195,16 +245,11 @@ class LaunchTimer:
             self.calls[n] = self.calls.get(n, 0) + live.count(n)
         if not self._sampled('merge_forward/%d' % stages):
             return None
-        import ctypes
-        from deepclr_amd import lib
         if self._hip is None:
-            self._hip = ctypes.CDLL('libamdhip64.so')
-        arr = (ctypes.c_void_p * lib.MERGE_EVENTS)()
-        for i in range(lib.MERGE_EVENTS):
-            ev = ctypes.c_void_p()
-            if self._hip.hipEventCreate(ctypes.byref(ev)) != 0:
-                return None
-            arr[i] = ev.value
+            self._hip = self._load_hip()
+        arr = self._raw_pool.pop() if self._raw_pool else self._new_raw()
+        if arr is None:
+            return None
         on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
         self.raw.append((arr, names, on_main))
         return arr
@@ -256,7 +301,7 @@ def algorithmic_work(name: str, cfg: dict):
         return 'mfma', 2.0 * m * n * kk, {}
     if base == 'head_conv_fused':
         pairs, pts = _dims(name)
-        dims = [264] + list(cfg['params']['output']['params']['mlp'])
+        dims = [3 + cfg['params']['merge']['params']['mlp'][-1]] + list(cfg['params']['output']['params']['mlp'])   # 259: the reference's input width, not the padded 264
         return 'mfma', 2.0 * pairs * pts * sum(a * b for a, b in zip(dims[:-1], dims[1:])), {}
     if base == 'flow_embedding':
         pairs, pts, k = _dims(name)
@@ -338,6 +383,17 @@ def parse_args(argv=None):
     ap.add_argument('--dense-group', type=int, default=None, choices=[0, 1],
                     help='1: the dense stages (flow embedding, head, FC tail) of the batches sampled together also run '
                          'as one launch sequence over group x B pairs')
+    ap.add_argument('--strict', action='store_true',
+                    help='no cross-batch fusion: --group 1 --dense-group 0 (every launch covers ONE batch of B pairs; '
+                         'sampling still runs `depth` batches ahead on side streams)')
+    ap.add_argument('--h2d', action='store_true',
+                    help="each step's batch is copied from pinned host memory inside the timed loop (copy stream)")
+    ap.add_argument('--clouds', default='gauss', choices=['gauss', 'ring'],
+                    help='gauss: SURVEY.md 8(d) Gaussian clouds (headline); ring: LiDAR-density ring scans (KITTI configs)')
+    ap.add_argument('--latency', action='store_true',
+                    help='one pair per ModelInferenceHelper.predict call (pairwise and sequential), per-pair ms')
+    ap.add_argument('--cpu-stub', action='store_true',
+                    help='no GPU: gloo process group and a stand-in compute function (tests of the multi-rank plumbing)')
     ap.add_argument('--gather-every', type=int, default=None,
                     help='steps whose outputs share one all-gather (N > 1); default: the dense group size, else 4')
     ap.add_argument('--force-dist', action='store_true',
@@ -345,9 +401,25 @@ def parse_args(argv=None):
     ap.add_argument('--ahead', default='knn', choices=['sample', 'features', 'knn'], help='stages run ahead')
     args = ap.parse_args(argv)
     wl = CONFIGS[args.config]
+    if args.strict:
+        if args.group not in (None, 1) or args.dense_group not in (None, 0):
+            ap.error('--strict fixes --group 1 --dense-group 0')
+        args.group, args.dense_group = 1, 0
     for key in ('steps', 'warmup', 'depth', 'group', 'dense_group'):
         if getattr(args, key) is None:
             setattr(args, key, wl[key])
+    if args.clouds == 'ring' and wl['kind'] != 'kitti':
+        ap.error('--clouds ring is a LiDAR scan: KITTI configurations (c2, c5) only')
+    if args.latency and (args.gpus != 1 or args.sequence or args.h2d):
+        ap.error('--latency is a single-GPU, single-pair mode')
+    if args.cpu_stub:
+        args.no_overlap = True                      # the stand-in has no stages to overlap
+    dense = bool(args.dense_group) and args.ahead == 'knn' and args.group > 1 and not args.no_overlap and not args.sequence
+    if dense and not args.latency and not args.alone_only and args.steps % args.group != 0:
+        # a dense (and a sampling) launch covers `group` batches and is enqueued at a group boundary only: a window that
+        # is not a whole number of groups would credit work it did not do (or do work it does not credit)
+        ap.error('--steps {} is not a multiple of --group {}: with dense groups the timed window must hold whole '
+                 'groups (use --steps {})'.format(args.steps, args.group, -(-args.steps // args.group) * args.group))
     return args
 
 
@@ -380,6 +452,93 @@ class OutputGather:
             self.filled = 0
 
 
+class StubModel:
+    """--cpu-stub: stands in for the model where there is no GPU. `rows` of outputs per step whose values encode
+    (rank, step), so that the all-gather's contents can be checked on every rank."""
+    label_dim = 8
+    npoint = 0
+
+    def __init__(self, rank: int, pairs: int):
+        self.rank, self.pairs, self.step_no = rank, pairs, 0
+
+    def __call__(self, x):
+        y = torch.full((self.pairs, self.label_dim), float(1000 * self.rank + self.step_no))
+        self.step_no += 1
+        return y, None, None
+
+    @staticmethod
+    def expected(rank: int, step: int) -> float:
+        return float(1000 * rank + step)
+
+
+def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool):
+    """max |M_hip - M_oracle| on the 4x4 for EVERY pair of the step (oracle on the host, outside the timed region)."""
+    import oracle
+    from oracle import labels as olabels
+    lt = LabelType.POSE3D_DUAL_QUAT
+    orc = oracle.build_oracle_model(cfg, sd)
+    x_cpu, y_cpu = x.cpu(), y.cpu().numpy()
+    deltas = []
+    n_out = y_cpu.shape[0]
+    for row in range(n_out):
+        if sequence:                                   # output row r pairs frames r, r + 1 of the chunk (row 0: carried frame)
+            if row == 0:
+                continue
+            clouds = [row - 1, row]
+        else:
+            clouds = [row, pairs_cfg + row]
+        y_ref = orc(x_cpu[clouds])
+        deltas.append(float(np.abs(lt.to_matrix(y_cpu[row]) - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max()))
+    return deltas
+
+
+def run_latency(args, model, cfg, sd, kind, points, dev):
+    """The reference's call pattern: ONE pair per call through ModelInferenceHelper.predict, timed as
+    /root/reference/scripts/timing.py:32-47 does (events around predict, synchronize, per-pair ms; the clouds are on the
+    device before the first event, as there)."""
+    from deepclr_amd.models import ModelInferenceHelper
+    x = torch.from_numpy(synthetic.make_batch(kind, 1, points)).to(dev)
+    out = {}
+    iters = max(args.steps, 20)
+    for seq in (False, True):
+        helper = ModelInferenceHelper(model, is_sequential=seq)
+        if seq:
+            helper.predict(x[0])
+        times = []
+        for i in range(args.warmup + iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            y = helper.predict(x[1]) if seq else helper.predict(x[1], x[0])
+            b.record()
+            torch.cuda.synchronize()
+            if i >= args.warmup:
+                times.append(a.elapsed_time(b))
+        times.sort()
+        out['sequential' if seq else 'pairwise'] = {
+            'median_ms': times[len(times) // 2], 'min_ms': times[0], 'p90_ms': times[int(0.9 * (len(times) - 1))],
+            'mean_ms': sum(times) / len(times), 'calls': len(times)}
+        if not seq:
+            y_pair = y
+    # wall-clock throughput of back-to-back calls without a synchronize in between (what a caller that only needs the
+    # poses at the end of a sequence gets)
+    helper = ModelInferenceHelper(model, is_sequential=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        helper.predict(x[1], x[0])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer = LaunchTimer(sample_every=1)
+    ops.TIMER = timer
+    for _ in range(5):
+        helper.predict(x[1], x[0])
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    kernels = {k: round(v['avg_us'], 1) for k, v in sorted(timer.summary().items())}
+    timer.close()
+    return out, y_pair, x, iters / elapsed, kernels
+
+
 def run(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -388,24 +547,68 @@ def run(args):
         raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
     wl = CONFIGS[args.config]
     kind, pairs_cfg, points = wl['kind'], wl['pairs'], wl['points']
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    cloud_kind = 'ring' if args.clouds == 'ring' else kind
+    stub = args.cpu_stub
+    if stub:
+        dev = torch.device('cpu')
+        sync = lambda: None                                                         # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+        sync = torch.cuda.synchronize
     dist = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
         if 'MASTER_ADDR' not in os.environ:
             os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1')
-        dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
+        if stub:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)          # nccl == RCCL on ROCm
 
     cfg = synthetic.model_cfg(kind)
-    sd = synthetic.random_state_dict(cfg, seed=0)
-    model = build_model(model_config_from_dict(cfg))
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
-    x = torch.from_numpy(synthetic.make_batch(kind, pairs_cfg, points, first_pair=rank * pairs_cfg)).to(dev)
+    sd = None
+    if stub:
+        model = StubModel(rank, pairs_cfg)
+        x = torch.zeros(2 * pairs_cfg, 4, cfg['input_dim'])
+        args.no_overlap, args.no_launch_timer, args.no_cpu_baseline = True, True, True
+    else:
+        sd = synthetic.random_state_dict(cfg, seed=0)
+        model = build_model(model_config_from_dict(cfg))
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+
+    if args.latency:
+        lat, y, x, back_to_back, kernels = run_latency(args, model, cfg, sd, cloud_kind, points, dev)
+        med = lat['pairwise']['median_ms']
+        result = {
+            'metric': 'scan-pairs/sec (2x{} pts)'.format(points), 'value': 1e3 / med, 'unit': 'scan-pairs/s',
+            'n_gpus': 1, 'steps': max(args.steps, 20), 'warmup': args.warmup, 'ms_per_step': med,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (matrix products: f16 hi/lo split operands, f32 accumulate)' if ops.PRECISION == 'f16x2' else 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'ONE {}-like scan pair per ModelInferenceHelper.predict call, 2x{} pts ({}; the '
+                                   "reference's own call pattern, scripts/timing.py:32-47); value = 1 / median per-pair "
+                                   'latency'.format(cloud_kind, points, wl['baseline']),
+                       'id': args.config, 'mode': 'latency', 'clouds': args.clouds, 'pairs_per_gpu': 1,
+                       'points_per_cloud': points, 'parallelism': 'dp1'},
+            'latency_ms': lat, 'back_to_back_pairs_per_s': back_to_back, 'kernels_us': kernels, 'roofline': None,
+        }
+        if not args.no_cpu_baseline:
+            result['pose_delta_vs_oracle'] = pose_deltas(y.view(1, -1), x, cfg, sd, 1, False)[0]
+            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points)
+        print(json.dumps(result), flush=True)
+        return
+
+    if not stub:
+        x_host = torch.from_numpy(synthetic.make_batch(cloud_kind, pairs_cfg, points, first_pair=rank * pairs_cfg))
+        x = x_host.to(dev)
+        if args.h2d:
+            x_host = x_host.pin_memory()
 
     pairs_per_step = pairs_cfg
+    feeder = None
     if args.sequence:
         if args.no_overlap:
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
@@ -418,8 +621,14 @@ def run(args):
         dense_group = bool(args.dense_group) and args.ahead == 'knn' and args.group > 1
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
                                                                group=args.group, dense_group=dense_group,
-                                                               inputs_ready=True)   # the batch is resident and never rewritten
-    if runner is not None:
+                                                               inputs_ready=True)   # resident and never rewritten, or
+                                                                                    # ordered by the feeder's copy events
+    if args.h2d:
+        if runner is None or args.sequence:
+            raise SystemExit('bench.py: --h2d runs through the pipelined runner')
+        feeder = HostBatchFeeder(runner, x)
+        feeder.fill([x_host] * (args.depth * args.group))
+    elif runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
 
@@ -439,14 +648,16 @@ def run(args):
         # the outputs go straight into the all-gather's send buffer where the runner allows it: one slot per step,
         # or the slots of a whole dense group at its first step
         out = None
-        if gather is not None and runner is not None and not args.sequence:
-            span = runner.group_start(x)
-            if span == 0 and in_place_left[0] == 0 and not runner._dense_group:
-                out, in_place_left[0] = gather.slot(), 1
-            elif span > 0 and gather.filled + span <= gather.every:
-                out = gather.send[gather.filled:gather.filled + span].view(span * pairs_per_step, -1)
-                in_place_left[0] = span
-        if runner is not None:
+        if feeder is not None:
+            y = feeder.step(x_host)
+        elif runner is not None:
+            if gather is not None and not args.sequence:
+                span = runner.group_start(x)
+                if span == 0 and in_place_left[0] == 0 and not runner._dense_group:
+                    out, in_place_left[0] = gather.slot(), 1
+                elif span > 0 and gather.filled + span <= gather.every:
+                    out = gather.send[gather.filled:gather.filled + span].view(span * pairs_per_step, -1)
+                    in_place_left[0] = span
             y = runner.step(x, upcoming=[x], out=out)
         else:
             with torch.no_grad():
@@ -463,13 +674,13 @@ def run(args):
         if gather is not None:
             gather.flush()
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def solo_pass(iters):
         """Untimed pass: the same launches one after another on one stream, so that each kernel's duration is its
         own (in the timed region they share the CUs with the sampler running ahead). Returns (per-kernel summary,
         mean barrier rounds of the sampler)."""
-        solo = LaunchTimer(sample_every=1)
+        solo = LaunchTimer(sample_every=1, raw_pool=2 * iters + 2)
         ops.TIMER = solo
         with torch.no_grad():
             g = args.group if (args.group > 1 and not args.sequence and runner is not None) else 1
@@ -497,22 +708,26 @@ def run(args):
                 sample = model.sample(xs)                      # (idx, group_pts, group_box): box[:, 0, 6] = barrier rounds
             if sample[2] is not None:
                 rounds = float(sample[2][:, 0, 6].mean())
-        return solo.summary(), rounds
+        summary = solo.summary()
+        solo.close()
+        return summary, rounds
 
     if args.alone_only:
         # profiling aid (profiles/collect.py): no timed window, only the launches one after another at the launch
         # sizes of the pipelined run -- a rocprofv3 kernel-stats summary of this command backs `alone_us`
         summary, rounds = solo_pass(args.alone_only)
         if rank == 0:
-            print(json.dumps({'alone_pass': True, 'config': args.config, 'iterations': args.alone_only,
+            print(json.dumps({'alone_pass': True, 'config': args.config, 'clouds': args.clouds, 'iterations': args.alone_only,
                               'kernels_alone_us': {k: round(v['avg_us'], 1) for k, v in summary.items()},
                               'fps_rounds': rounds}))
         return
 
     for _ in range(args.warmup):
         y = step()
-    timer = None if args.no_launch_timer else LaunchTimer()
+    # launches that cover < 64 pairs come several per step: bracket every third (events on all of them cost ~10 %)
+    timer = None if args.no_launch_timer else LaunchTimer(sample_every=3 if args.group * pairs_cfg < 64 else 1)
     ops.TIMER = timer
+    copied0 = feeder.bytes_copied if feeder is not None else 0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -530,13 +745,24 @@ def run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    gather_check = None
+    if stub and gather is not None:
+        # every rank's block of the last flushed all-gather must hold that rank's values for the steps it covered
+        # (the fence after the warm-up flushes, so slots count from the start of the timed window)
+        covered = args.steps % gather.every or gather.every
+        first = args.warmup + args.steps - covered
+        got = gather.gathered.view(world, gather.every, pairs_per_step, -1)
+        gather_check = all(bool((got[r, s] == StubModel.expected(r, first + s)).all())
+                           for r in range(world) for s in range(covered))
+
     if rank == 0:
         pairs_total = world * pairs_per_step * args.steps
-        roofline, kernels, rooflines = None, None, None
+        roofline, kernels, rooflines, roofline_sampler = None, None, None, None
         traffic_all, traffic_src = load_traffic()
-        traffic = traffic_all.get(args.config, {})
+        traffic = traffic_all.get(args.config if args.clouds == 'gauss' else args.config + '_' + args.clouds, {})
         if timer is not None:
             kernels = timer.summary()
+            timer.close()
 
             def roof(name):
                 bound, units, extra = algorithmic_work(name, cfg)
@@ -573,28 +799,39 @@ def run(args):
                        # this kernel's launches in the timed region x its average duration / the region
                        'share_of_step': kernels[name]['avg_us'] * 1e-6 * kernels[name]['launches'] / elapsed,
                        'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
+                if solo_us is not None:        # CU-time: what the launch costs the chip when it runs alone
+                    out['cu_us_per_pair_alone'] = solo_us * min(1.0, _workgroups(name, cfg) / 256.0) / _pairs_in(name)
                 out.update(extra)
                 return out
 
-            # dominant kernel = largest total time on the stream that bounds the step (the main one);
-            # the side-stream sampler is latency-bound by construction and listed in `rooflines`
+            # `roofline` = the dominant MFMA/HBM kernel on the stream that bounds the step (the main one);
+            # `roofline_sampler` = the sampler, the largest consumer of kernel time overall: a latency chain on the side
+            # streams, priced as such. `rooflines` lists the eight largest of all streams.
             main = [k for k in kernels if kernels[k]['main_stream']] or list(kernels)
             weight = lambda k: kernels[k]['avg_us'] * kernels[k]['launches']            # noqa: E731
             roofline = roof(max(main, key=weight))
+            fps = [k for k in kernels if kernel_base(k) == 'fps_clouds']
+            if fps:
+                roofline_sampler = roof(max(fps, key=weight))
             rooflines = [roof(k) for k in sorted(kernels, key=lambda k: -weight(k))[:8]]
+        mode = ('sequence' if args.sequence else 'strict' if (args.group == 1 and not args.no_overlap) else
+                'serial' if args.no_overlap else 'grouped')
         result = {
             'metric': 'scan-pairs/sec (2x{} pts)'.format(points), 'value': pairs_total / elapsed, 'unit': 'scan-pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 (matrix products: f16 hi/lo split operands, f32 accumulate)' if ops.PRECISION == 'f16x2' else 'f32', 'data': 'synthetic',
+            'dtype': 'f32 (matrix products: f16 hi/lo split operands, f32 accumulate)' if ops.PRECISION == 'f16x2' else 'f32',
+            'data': 'cpu-stub: NO model ran, multi-rank plumbing only -- not a measurement' if stub else 'synthetic',
             'config': {'workload': ('odometry chunks of {0} consecutive {3}-like frames ({4} pts x {5} ch) = {1} pairs'
                                     '/GPU/step, each frame sampled once; NOT the BASELINE metric'
                                     if args.sequence else
                                     '{3}-like scan pairs, 2x{4} pts x {5} ch, {1} pairs/GPU/step ({2})')
-                                   .format(x.shape[0], pairs_per_step, wl['baseline'], kind, points, x.shape[2])
+                                   .format(x.shape[0], pairs_per_step, wl['baseline'], cloud_kind, points, x.shape[2])
                                    + '; {} architecture, seeded random weights'.format(
                                        'kitti_00-06' if kind == 'kitti' else 'modelnet40'),
-                       'id': args.config, 'pairs_per_gpu': pairs_per_step, 'points_per_cloud': points,
+                       'id': args.config, 'mode': mode, 'clouds': args.clouds,
+                       'input': 'pinned host memory, copied every step inside the loop' if args.h2d else 'resident in HBM',
+                       'pairs_per_gpu': pairs_per_step, 'points_per_cloud': points,
                        'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
                        'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
@@ -606,26 +843,45 @@ def run(args):
                                                          'bytes_per_rank': int(gather.send.numel() * 4)},
             'roofline': roofline,
         }
+        if feeder is not None:
+            copied = feeder.bytes_copied - copied0
+            result['h2d'] = {'bytes_per_step': copied / args.steps, 'gb_per_s': copied / elapsed / 1e9}
+        if gather_check is not None:
+            result['gather_check'] = gather_check
+        if roofline_sampler is not None:
+            result['roofline_sampler'] = roofline_sampler
         if rooflines is not None:
             result['rooflines'] = rooflines
             result['traffic_source'] = traffic_src
         if kernels is not None:
             result['kernels_us'] = {k: round(v['avg_us'], 1) for k, v in sorted(kernels.items())}
         if world == 1 and not args.no_cpu_baseline:
-            # pose check of the last step's first pair against the oracle (outside the timed region)
-            import oracle
-            from oracle import labels as olabels
-            first = [0, 1] if args.sequence else [0, pairs_cfg]          # clouds of output row `row`
-            row = 1 if args.sequence else 0
-            y_ref = oracle.build_oracle_model(cfg, sd)(x[first].cpu())
-            lt = LabelType.POSE3D_DUAL_QUAT
-            result['pose_delta_vs_oracle'] = float(np.abs(lt.to_matrix(y[row].cpu().numpy())
-                                                          - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max())
-            result['cpu_baseline'] = cpu_baseline(cfg, sd, kind, points)
+            # pose check of EVERY pair of the last step against the oracle (outside the timed region)
+            deltas = pose_deltas(y, x, cfg, sd, pairs_cfg, args.sequence)
+            result['pose_delta_vs_oracle'] = float(np.mean(deltas))
+            result['pose_delta_max'] = float(np.max(deltas))
+            result['pose_delta_pairs'] = len(deltas)
+            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pairs_in(name: str) -> float:
+    """Scan pairs one launch of this span serves (clouds / 2 for the per-cloud stages)."""
+    d = _dims(name)
+    base = kernel_base(name)
+    if base in ('fps_clouds', 'sa_msg_fused'):
+        return d[0] / 2.0
+    if base == 'linear_pair':
+        return 1.0
+    return float(d[0])
+
+
+def _workgroups(name: str, cfg: dict) -> float:
+    """Workgroup count of the launch where it is below a full chip (the sampler: one per cloud); else 256."""
+    return float(_dims(name)[0]) if kernel_base(name) == 'fps_clouds' else 256.0
 
 
 def main(argv=None):

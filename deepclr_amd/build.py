@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libdeepclr_amd.so')
-SOURCES = ['api.hip', 'fps.hip', 'grouping.hip', 'knn.hip', 'sa.hip', 'gemm.hip', 'flow.hip', 'gemm16.hip', 'headreg.hip', 'flow16.hip', 'prep.hip', 'forward.hip']
+SOURCES = ['api.hip', 'fps.hip', 'grouping.hip', 'knn.hip', 'sa.hip', 'gemm.hip', 'flow.hip', 'gemm16.hip', 'flow16.hip', 'prep.hip', 'forward.hip']
 HEADERS = ['common.h', 'mma.h', 'mma16f.h', os.path.join('..', '..', 'include', 'deepclr_amd.h')]
 # -ffp-contract=off: the distance recipe shared with the oracle is one rounding per operation;
 # MLP code requests FMA explicitly.

@@ -8,7 +8,9 @@
 //           split and stored in place as half-octets of layer 3's input;
 //   layer 3 computes H2 * W3^T -- lane = channel, lane-quarter = template point, registers = its 4
 //           neighbours of the tile, so mask + max over the k neighbours stays in registers.
+#ifdef DCLR_ABLATION
 #include <stdlib.h>
+#endif
 
 #include "mma16f.h"
 
@@ -274,13 +276,17 @@ extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float
     DCLR_REQUIRE(((uintptr_t)w2p & 15) == 0 && ((uintptr_t)w3p & 15) == 0 && ((uintptr_t)pt & 7) == 0 &&
                  ((uintptr_t)ps & 7) == 0 && ((uintptr_t)b2 & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    static const int abl = getenv("DCLR_FLOW_ABL") ? atoi(getenv("DCLR_FLOW_ABL")) : 0;      // measurement switch (k = 20 only)
+#ifdef DCLR_ABLATION
+    // Measurement builds only (-DDCLR_ABLATION, a separate .so selected with DCLR_LIB; scratch/flow_probe.py): the
+    // timing-only variants return WRONG rows. The product library is compiled without them and reads no environment.
+    static const int abl = getenv("DCLR_FLOW_ABL") ? atoi(getenv("DCLR_FLOW_ABL")) : 0;      // k = 20 only
     if (abl != 0 && (k + 3) / 4 == 5) {
 #define DCLR_FLOW16_ABL(A) case A: flow16_launch<5, A>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
         switch (abl) { DCLR_FLOW16_ABL(1); DCLR_FLOW16_ABL(2); DCLR_FLOW16_ABL(3); DCLR_FLOW16_ABL(4); DCLR_FLOW16_ABL(6); default: break; }
 #undef DCLR_FLOW16_ABL
         return dclr_launch_status();
     }
+#endif
 #define DCLR_FLOW16_CASE(T) case T: flow16_launch<T>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
     switch ((k + 3) / 4) {
         DCLR_FLOW16_CASE(1); DCLR_FLOW16_CASE(2); DCLR_FLOW16_CASE(3); DCLR_FLOW16_CASE(4);

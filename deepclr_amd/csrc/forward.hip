@@ -49,10 +49,7 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
         (void)hipGetLastError();                            // consume the sticky copy; the code below carries the error
         return -(1000 + (int)ms);
     }
-    if (a->precision == 1 && a->head_reg_w && a->head_reg_bias && a->npoint % 64 == 0)
-        rc = dclr_head_conv_reg_f16(rows, a->head_k_in, a->head_reg_w, a->head_reg_bias, a->e_rows, DCLR_E_STRIDE, a->colmax,
-                                    a->npoint, stream);
-    else if (a->precision == 1)
+    if (a->precision == 1)
         rc = dclr_head_conv_fused_f16(rows, a->n_head_layers, a->head_k_in, a->head_k, a->head_n, a->head_w, a->head_b,
                                       a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);
     else

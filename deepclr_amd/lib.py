@@ -44,9 +44,6 @@ SIGNATURES = {
     'dclr_pack_weight_f16': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_head_conv_fused_f16': [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     'dclr_flow_embedding_fused_f16': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
-    'dclr_head_reg_packed_bytes': [],
-    'dclr_head_reg_pack': [_i, _p, _p, _p, _p, _p, _p],
-    'dclr_head_conv_reg_f16': [_i, _i, _p, _p, _p, _i, _p, _i, _p],
     'dclr_merge_forward': [_p, _p, _p],
     'dclr_prepare_cloud_blocks': [_i, _i, _i],
     'dclr_prepare_cloud': [_i, _i, _p, _i, _i, _f, _f, _i, _p, _p, _p, _p],
@@ -67,7 +64,6 @@ class MergeArgs(ctypes.Structure):
         ('head_w', _p * MERGE_MAX_LAYERS), ('head_b', _p * MERGE_MAX_LAYERS),
         ('fc_w', _p * MERGE_MAX_FC), ('fc_b', _p * MERGE_MAX_FC),
         ('pt', _p), ('ps', _p), ('knn_idx', _p), ('e_rows', _p), ('colmax', _p), ('fc_tmp', _p * 2), ('y', _p),
-        ('head_reg_w', _p), ('head_reg_bias', _p),
     ]
 
 
@@ -87,7 +83,7 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = (ctypes.c_char_p if name == 'dclr_error_string'
-                          else ctypes.c_longlong if name in ('dclr_fps_workspace_bytes', 'dclr_head_reg_packed_bytes')
+                          else ctypes.c_longlong if name == 'dclr_fps_workspace_bytes'
                           else _i)
         _lib = lib
     return _lib

@@ -232,32 +232,9 @@ class OutputSimple(DeepCLRModule):
         self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
         self._cache = PackedCache()
         self._cache16 = PackedCache()
-        self._cache_reg = PackedCache()
 
     def output_dim(self) -> int:
         return self._label_type.dim
-
-    def _packed_reg(self):
-        """(weight stream, biases) of the register-resident conv chain, or None when it is not selected
-        (DCLR_HEAD_REG=1; off by default: measured no faster than the LDS-resident chain) or the
-        layer widths are not the reference architecture's (dclr_head_conv_reg_f16 is built for
-        259 -> 256 -> 256 -> 512 -> 512 -> 1024)."""
-        params = self.conv.affine_params()
-        if [w.shape[0] for w, _ in params] != ops.HEAD_REG_WIDTHS or any(b is None for _, b in params) \
-                or os.environ.get('DCLR_HEAD_REG', '0') != '1':
-            return None
-
-        def build():
-            dev = params[0][0].device
-            kmap = torch.full((ops.HEAD_REG_K0,), -1, dtype=torch.int32, device=dev)
-            kmap[:256] = torch.arange(3, 259, dtype=torch.int32, device=dev)       # rows E: [feat | xyz | pad]
-            kmap[256:259] = torch.arange(0, 3, dtype=torch.int32, device=dev)
-            packed = ops.head_reg_pack([w for w, _ in params], kmap)
-            return packed, torch.cat([b.detach().reshape(-1) for _, b in params]).contiguous()
-        return self._cache_reg.get(list(self.conv.parameters()), build)
-
-    def _use_reg(self, rows: int, pairs: int) -> bool:
-        return ops.PRECISION == 'f16x2' and rows % 64 == 0 and (rows // pairs) % 64 == 0 and self._packed_reg() is not None
 
     def _packed(self):
         def build():
@@ -308,10 +285,7 @@ class OutputSimple(DeepCLRModule):
     def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         layers = self._packed()
         if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
-            if self._use_reg(e_rows.shape[0], pairs):
-                packed, bias = self._packed_reg()
-                g = ops.head_conv_reg_f16(e_rows, ops.E_STRIDE, packed, bias, pairs)
-            elif ops.PRECISION == 'f16x2':
+            if ops.PRECISION == 'f16x2':
                 g = ops.head_conv_fused_f16(e_rows, ops.E_STRIDE, self._packed_f16(), pairs)
             else:
                 g = ops.head_conv_fused(e_rows, layers, pairs)               # conv chain + max over points
@@ -462,10 +436,6 @@ class _MergePlan:
         a.pt, a.ps, a.knn_idx, a.e_rows = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr(), ws['e'].data_ptr()
         a.colmax = ws['colmax'].data_ptr()
         a.fc_tmp[0], a.fc_tmp[1] = ws['tmp'][0].data_ptr(), ws['tmp'][1].data_ptr()
-        if f16 and head._use_reg(rows, pairs):
-            reg = head._packed_reg()
-            keep['tensors'].append(reg)
-            a.head_reg_w, a.head_reg_bias = reg[0].data_ptr(), reg[1].data_ptr()
         return cls(a, keep, cls._version_key(keep['mods']), pairs, fcs[-1][0].shape[0], device)
 
     PREP_RING = 3
@@ -540,6 +510,7 @@ class DeepCLR(BaseModel):
         self._cloud_layers = nn.Sequential(cloud)
         self._merge_layers = nn.Sequential(merge_layer, head)
         self._plans: Dict[Any, Any] = {}
+        self._range_ok = None                       # weights key of the last checked forward that passed (ops.CHECK_RANGE)
         if loss is None:
             self._loss_layer = None
         elif isinstance(loss, list):
@@ -594,7 +565,7 @@ class DeepCLR(BaseModel):
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
-        if ops.CHECK_RANGE and ops.PRECISION == 'f16x2':
+        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and (ops.CHECK_RANGE == 'always' or self._range_unchecked()):
             return self._merge_rows_checked(f_rows, pairs, out)
         plan = self._merge_plan(f_rows, pairs)
         if plan is not None:
@@ -606,9 +577,17 @@ class DeepCLR(BaseModel):
         y = self._merge_layers[1].forward_rows(e_rows, pairs)
         return y if out is None else out.copy_(y)
 
+    def _range_key(self):
+        return tuple((p.data_ptr(), p._version) for m in self._merge_layers for p in m.parameters())
+
+    def _range_unchecked(self) -> bool:
+        """True until a checked forward has passed for the current weights (any in-place change bumps a version)."""
+        return self._range_ok != self._range_key()
+
     def _merge_rows_checked(self, f_rows: torch.Tensor, pairs: int, out: Optional[torch.Tensor]) -> torch.Tensor:
-        """DCLR_CHECK_RANGE=1: the dense stages on the split-f16 path AND on the f32 matrix instructions; raises when an
-        operand left the f16 range (the split path clamps at +-65504 and would return wrong poses silently)."""
+        """The dense stages on the split-f16 path AND on the f32 matrix instructions; raises when an operand left the f16
+        range (the split path clamps at +-65504 and would return wrong poses silently). Runs on the first forward after
+        the weights changed (ops.CHECK_RANGE = 'first', the default: two host syncs, once) or on every forward ('always')."""
         flow, head = self._merge_layers[0], self._merge_layers[1]
         e16 = flow.forward_rows(f_rows, pairs, self.npoint)
         y16 = head.forward_rows(e16, pairs)
@@ -624,6 +603,7 @@ class DeepCLR(BaseModel):
             raise RuntimeError("split-f16 matrix path out of range: activations reach {:.4g} (limit 65504) and the pose "
                                "outputs differ from the f32 matrix path by {:.3g}; run this checkpoint with "
                                "DCLR_PRECISION=f32".format(peak, err))
+        self._range_ok = self._range_key()
         return y16 if out is None else out.copy_(y16)
 
     def _merge_plan(self, f_rows: torch.Tensor, pairs: int):

@@ -127,22 +127,44 @@ class PackedCache:
         self._value = None
         self._event = None
         self._stream = None
+        self._users = set()                 # streams (other than the builder's) that have been handed the value
+
+    @staticmethod
+    def _tensors(obj):
+        if torch.is_tensor(obj):
+            yield obj
+        elif isinstance(obj, dict):
+            for o in obj.values():
+                yield from PackedCache._tensors(o)
+        elif isinstance(obj, (tuple, list)):
+            for o in obj:
+                yield from PackedCache._tensors(o)
 
     def get(self, params, build):
         key = tuple((p.device, p.data_ptr(), p._version) for p in params)
+        cuda = bool(params) and params[0].is_cuda
         if key != self._key:
+            # the buffers being replaced may still be read by launches other streams have enqueued: their memory goes
+            # back to the allocator only behind those streams' work (record_stream was called when they were handed out)
             self._value = build()
             self._key = key
             self._event, self._stream = None, None
-            if params and params[0].is_cuda:
+            self._users = set()
+            if cuda:
                 self._stream = torch.cuda.current_stream(params[0].device).cuda_stream
                 self._event = torch.cuda.Event()
                 self._event.record()
-        elif self._event is not None:
-            if self._event.query():
-                self._event = None                              # packing finished: visible to every stream
-            else:
-                cur = torch.cuda.current_stream()
-                if cur.cuda_stream != self._stream:
-                    cur.wait_event(self._event)
+        elif cuda:
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream != self._stream:
+                if cur.cuda_stream not in self._users:          # first hand-out to this stream
+                    self._users.add(cur.cuda_stream)
+                    for t in self._tensors(self._value):
+                        if t.is_cuda:
+                            t.record_stream(cur)
+                if self._event is not None:
+                    if self._event.query():
+                        self._event = None                      # packing finished: visible to every stream
+                    else:
+                        cur.wait_event(self._event)
         return self._value

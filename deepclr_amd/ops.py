@@ -27,10 +27,14 @@ TIMER = None
 PRECISION = os.environ.get('DCLR_PRECISION', 'f16x2')
 
 # Split-f16 operands saturate at +-65504 (csrc/mma16f.h clamps instead of producing inf). Weights are checked when they
-# are packed; activations cannot be checked inside the fused kernels for free, so CHECK_RANGE (DCLR_CHECK_RANGE=1) makes
-# every forward ALSO run the dense stages on the f32 matrix instructions and raise if the two disagree -- a debugging
-# mode for new checkpoints, not for production throughput.
-CHECK_RANGE = os.environ.get('DCLR_CHECK_RANGE', '0') == '1'
+# are packed; activations cannot be checked inside the fused kernels for free. CHECK_RANGE (DCLR_CHECK_RANGE):
+#   'first' (default)  the FIRST forward after the weights changed (load_state_dict, .to(), an optimizer step) also runs
+#                      the dense stages on the f32 matrix instructions, on that call's own activations, and raises if the
+#                      two disagree or an activation leaves the range: a new checkpoint cannot clamp silently on first use;
+#   'always' (or '1')  every forward does (debugging; halves throughput);
+#   'never' (or '0')   no check.
+CHECK_RANGE = {'1': 'always', '0': 'never'}.get(os.environ.get('DCLR_CHECK_RANGE', 'first'),
+                                                os.environ.get('DCLR_CHECK_RANGE', 'first'))
 F16_MAX = 65504.0
 
 
@@ -321,37 +325,6 @@ def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torc
     _call('dclr_head_conv_fused_f16', 'head_conv_fused[%dx%d]' % (groups, m // groups), m, nl, int(k_in), ctypes.cast(k_h, ctypes.c_void_p),
           ctypes.cast(n_h, ctypes.c_void_p), ctypes.cast(w_h, ctypes.c_void_p), ctypes.cast(b_h, ctypes.c_void_p),
           x.data_ptr(), ldx, out.data_ptr(), m // groups, lib.stream_ptr())
-    return out
-
-
-HEAD_REG_WIDTHS = [256, 256, 512, 512, 1024]        # the conv chain dclr_head_conv_reg_f16 is built for
-HEAD_REG_K0 = 288
-
-
-def head_reg_pack(weights: Sequence[torch.Tensor], kmap0: torch.Tensor) -> torch.Tensor:
-    """Row-major conv weights of the five head layers -> the LDS-ring stream of dclr_head_conv_reg_f16."""
-    ws = [lib.dev_f32(w.detach().reshape(w.shape[0], -1).contiguous(), 'w') for w in weights]
-    for w in ws:
-        check_f16_range(w, 'head_reg_pack')
-    assert kmap0.dtype == torch.int32 and kmap0.numel() == HEAD_REG_K0 and kmap0.is_cuda
-    nl = len(ws)
-    k_h = (ctypes.c_int * nl)(*[int(w.shape[1]) for w in ws])
-    n_h = (ctypes.c_int * nl)(*[int(w.shape[0]) for w in ws])
-    w_h = (ctypes.c_void_p * nl)(*[w.data_ptr() for w in ws])
-    nbytes = lib.load().dclr_head_reg_packed_bytes()
-    packed = torch.empty(nbytes // 4, dtype=torch.int32, device=ws[0].device)
-    _call('dclr_head_reg_pack', 'head_reg_pack', nl, ctypes.cast(k_h, ctypes.c_void_p), ctypes.cast(n_h, ctypes.c_void_p),
-          ctypes.cast(w_h, ctypes.c_void_p), kmap0.data_ptr(), packed.data_ptr(), lib.stream_ptr())
-    return packed
-
-
-def head_conv_reg_f16(x: torch.Tensor, k_in: int, packed: torch.Tensor, bias: torch.Tensor, groups: int) -> torch.Tensor:
-    """x rows (m, ldx) -> (groups, 1024) column maxima through the register-resident conv chain."""
-    x = lib.dev_f32(x, 'x')
-    m, ldx = x.shape
-    out = torch.zeros(groups, HEAD_REG_WIDTHS[-1], dtype=torch.float32, device=x.device)
-    _call('dclr_head_conv_reg_f16', 'head_conv_fused[%dx%d]' % (groups, m // groups), m, int(k_in), packed.data_ptr(),
-          lib.dev_f32(bias, 'bias').data_ptr(), x.data_ptr(), ldx, out.data_ptr(), m // groups, lib.stream_ptr())
     return out
 
 

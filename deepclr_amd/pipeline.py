@@ -59,11 +59,18 @@ class PipelinedForward:
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
+        self._ready = {}                            # id(batch) -> event its producer recorded (prefetch(ready=...))
+        self.prefetched = 0                         # batches accepted by prefetch() so far (feeders watch this)
 
-    def prefetch(self, x: torch.Tensor, flush: bool = True) -> None:
+    def prefetch(self, x: torch.Tensor, flush: bool = True, ready: Optional[torch.cuda.Event] = None) -> None:
         """Start sampling for `x` (2B, N, C) on the next side stream (with group > 1: once `group` batches have
-        been handed in, or at once if flush)."""
+        been handed in, or at once if flush). ready: an event after which `x` is complete in memory (e.g. recorded
+        behind its host-to-device copy on a copy stream); the sampling launch waits for it -- with inputs_ready this
+        is the only ordering between the batch's producer and its consumers."""
         self._waiting.append(x)
+        self.prefetched += 1
+        if ready is not None:
+            self._ready[id(x)] = ready
         if flush or (len(self._waiting) >= self.group and not self._hold_launch):
             self._launch()
 
@@ -77,6 +84,10 @@ class PipelinedForward:
         self._next_stream = (self._next_stream + 1) % self.depth
         if not self._inputs_ready:
             side.wait_stream(main)                           # the batches (and anything producing them) are ready
+        for b in xs:
+            ev = self._ready.pop(id(b), None)
+            if ev is not None:
+                side.wait_event(ev)
         with torch.cuda.stream(side), torch.no_grad():
             if len(xs) == 1:
                 out = self._model.sample(xs[0])
@@ -180,6 +191,10 @@ class PipelinedForward:
             if self.in_flight() >= self.depth * self.group:
                 break
             self.prefetch(nxt, flush=False)
+        if ready is None:                                    # never sampled ahead: everything runs here, behind its producer
+            ev = self._ready.pop(id(x), None)
+            if ev is not None:
+                main.wait_event(ev)
         with torch.no_grad():
             prep = None
             if self._ahead == 'knn' and ready is not None:
@@ -220,10 +235,10 @@ class PipelinedForward:
             return
         self.prefetch(window[0])
         while window:
-            cur = window.popleft()
+            started = self.in_flight()                       # counted while `cur` is still window[0]: window[:started] are
+            cur = window.popleft()                           # the batches already handed to prefetch()
             refill()
-            started = self.in_flight()
-            yield self.step(cur, list(window)[started:])
+            yield self.step(cur, list(window)[max(0, started - 1):])
 
 
 class PipelinedSequence(PipelinedForward):
@@ -247,3 +262,66 @@ class PipelinedSequence(PipelinedForward):
         if pairs == 0:
             return f_rows.new_empty(0, self._model.label_dim)
         return self._model.merge_rows(pair_rows, pairs, out=out)
+
+
+class HostBatchFeeder:
+    """Batches that live in (pinned) HOST memory, copied to the device inside the loop on a copy stream of their own, so
+    that the transfer of batch i + depth * group overlaps the kernels of batch i -- what the reference does per pair with
+    a blocking `.cuda()` (/root/reference/scripts/inference.py:89-90). A ring of device buffers receives the copies;
+    a buffer is rewritten only after the step that consumed its previous contents has been enqueued (an event on the
+    caller's stream, which by then has waited for the sampling launch that read the buffer). The sampling launch of a
+    batch waits for the event recorded behind its copy (PipelinedForward.prefetch(ready=...))."""
+
+    def __init__(self, runner: PipelinedForward, example: torch.Tensor, slots: Optional[int] = None):
+        self._runner = runner
+        n = slots if slots is not None else runner.depth * runner.group + runner.group + 2
+        self._ring = [torch.empty_like(example, device=torch.cuda.current_device()) for _ in range(n)]
+        self._free_after = [None] * n               # event: previous contents consumed
+        self._copy = torch.cuda.Stream()
+        self._next = 0
+        self._queue: Deque[Tuple[int, torch.Tensor]] = deque()     # copied (or copying), not yet stepped: (slot, tensor)
+        self._offered = 0                           # how many of _queue the runner has taken into prefetch()
+        self.bytes_copied = 0
+
+    def _upload(self, host: torch.Tensor) -> None:
+        slot = self._next
+        self._next = (self._next + 1) % len(self._ring)
+        if any(s == slot for s, _ in self._queue):
+            raise RuntimeError("HostBatchFeeder: ring too small for the batches in flight")
+        dst = self._ring[slot]
+        if self._free_after[slot] is not None:
+            self._copy.wait_event(self._free_after[slot])
+        with torch.cuda.stream(self._copy):
+            dst.copy_(host, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._copy)
+        self.bytes_copied += host.numel() * host.element_size()
+        self._queue.append((slot, dst))
+        self._runner._ready[id(dst)] = ready        # picked up by whichever prefetch() takes the batch
+
+    def fill(self, host_batches: Iterable[torch.Tensor]) -> None:
+        """Upload and start sampling for as many of `host_batches` as the pipeline holds (call once before the loop)."""
+        for h in host_batches:
+            if self._runner.in_flight() >= self._runner.depth * self._runner.group:
+                break
+            self._upload(h)
+            self._runner.prefetch(self._queue[-1][1], flush=False)
+            self._offered += 1
+
+    def step(self, next_host: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Results of the oldest uploaded batch; `next_host` (pinned host tensor, or None at the end of a stream) is
+        uploaded first so that its copy runs beside this batch's kernels."""
+        if next_host is not None and len(self._queue) < len(self._ring) - 1:
+            self._upload(next_host)
+        slot, cur = self._queue[0]
+        before, cur_offered = self._runner.prefetched, self._offered > 0
+        upcoming = [t for _, t in list(self._queue)[max(1, self._offered):]]
+        y = self._runner.step(cur, upcoming=upcoming, out=out)
+        self._offered += self._runner.prefetched - before
+        self._queue.popleft()
+        if cur_offered:
+            self._offered -= 1
+        ev = torch.cuda.Event()
+        ev.record()                                  # caller's stream: it has waited for the launch that read `cur`
+        self._free_after[slot] = ev
+        return y

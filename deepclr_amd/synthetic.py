@@ -88,10 +88,58 @@ def modelnet_like_pair(i: int, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarr
     return p.astype(np.float32), src.astype(np.float32), m
 
 
+def ring_scan(rng: np.random.Generator, n: int, rings: int = 64) -> np.ndarray:
+    """A spinning-LiDAR scan with KITTI's sampling density and no dataset: `rings` beams between +2 and -24.8 degrees
+    of elevation (HDL-64E), sensor 1.73 m above a flat ground, 2 n / rings azimuth steps per revolution of which
+    every second one is kept (the reference's converter drops every second point of a raw scan,
+    /root/reference/scripts/converter/kitti_odometry.py:14,22) -> exactly n points (n, 4) in scan order, ring by
+    ring. A beam ends on the ground (range = height / sin(-elevation): the dense near field), on one of two facades
+    of a street canyon, on one of a few dozen car-sized boxes, or at the 80 m range limit. Near the sensor a 1 m
+    ball holds several hundred points -- the regime where ball query reaches its nsample caps; the Gaussian clouds
+    of kitti_like_pair hold ~20."""
+    per_ring = 2 * n // rings
+    assert per_ring * rings == 2 * n, "n must be a multiple of rings / 2"
+    elev = np.deg2rad(np.linspace(2.0, -24.8, rings))[:, None]                       # (rings, 1)
+    azim = (2.0 * np.pi / per_ring) * np.arange(per_ring)[None, :] + rng.uniform(0, 2 * np.pi)
+    dx, dy, dz = np.cos(elev) * np.cos(azim), np.cos(elev) * np.sin(azim), np.sin(elev) * np.ones_like(azim)
+    height, far = 1.73, 80.0
+    rng_ground = np.where(dz < -1e-3, height / np.maximum(-dz, 1e-3), far)
+    half_width = rng.uniform(7.0, 14.0, size=2)                                      # facades at y = +w0, y = -w1
+    rng_wall = np.where(dy > 1e-3, half_width[0] / np.maximum(dy, 1e-3),
+                        np.where(dy < -1e-3, half_width[1] / np.maximum(-dy, 1e-3), far))
+    dist = np.minimum(np.minimum(rng_ground, rng_wall), far)
+    for _ in range(24):                                                              # parked cars: 4.2 x 1.8 x 1.5 m boxes
+        cx, cy = rng.uniform(-40, 40), rng.choice([-1, 1]) * rng.uniform(2.5, 6.0)
+        lo = np.array([cx - 2.1, cy - 0.9, -height]); hi = np.array([cx + 2.1, cy + 0.9, -height + 1.5])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t0 = np.stack([lo[0] / dx, lo[1] / dy, lo[2] / dz]); t1 = np.stack([hi[0] / dx, hi[1] / dy, hi[2] / dz])
+        tn, tf = np.nanmax(np.minimum(t0, t1), axis=0), np.nanmin(np.maximum(t0, t1), axis=0)
+        hit = (tn <= tf) & (tn > 0.5)
+        dist = np.where(hit, np.minimum(dist, tn), dist)
+    dist = dist * (1.0 + rng.normal(0.0, 0.002, size=dist.shape))                     # range noise, 2 mm per metre
+    pts = np.stack([dx * dist, dy * dist, dz * dist, rng.uniform(0.0, 1.0, size=dist.shape)], axis=-1)
+    return pts[:, ::2, :].reshape(-1, 4)                                             # every 2nd point, ring-major order
+
+
+def ring_pair(i: int, n: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """LiDAR-density counterpart of kitti_like_pair: template = ring_scan, source = the same small rigid motion +
+    1 cm noise + permutation."""
+    rng = np.random.default_rng(4321 + i)
+    tmpl = ring_scan(rng, n)
+    rot = _euler_to_mat(*np.deg2rad(rng.normal(0.0, [0.1, 0.1, 1.0])))
+    trans = rng.normal(0.0, [0.2, 0.02, 0.02])
+    src = tmpl.copy()
+    src[:, :3] = tmpl[:, :3] @ rot.T + trans + rng.normal(0.0, 0.01, size=(n, 3))
+    src = src[rng.permutation(n)]
+    m = np.eye(4)
+    m[:3, :3], m[:3, 3] = rot, trans
+    return tmpl.astype(np.float32), src.astype(np.float32), m
+
+
 def make_batch(kind: str, n_pairs: int, n_points: int, first_pair: int = 0) -> np.ndarray:
     """(2B, N, C) float32 in the reference batch layout [T0..TB-1, S0..SB-1]
-    (/root/reference/deepclr/data/build.py:82)."""
-    gen = {'kitti': kitti_like_pair, 'modelnet': modelnet_like_pair}[kind]
+    (/root/reference/deepclr/data/build.py:82). kind 'ring': KITTI architecture on ring_pair clouds."""
+    gen = {'kitti': kitti_like_pair, 'modelnet': modelnet_like_pair, 'ring': ring_pair}[kind]
     pairs = [gen(first_pair + i, n_points) for i in range(n_pairs)]
     return np.stack([p[0] for p in pairs] + [p[1] for p in pairs], axis=0)
 

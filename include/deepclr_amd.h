@@ -226,25 +226,6 @@ int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, co
                                   const float *b1, const void *w2p, const float *b2, const void *w3p,
                                   const float *b3, float *e_rows, dclr_stream_t stream);
 
-/* ---- register-resident pose head (deepclr_amd/csrc/headreg.hip) -------------------------------------------
- * The same operator as dclr_head_conv_fused_f16 (reference: OutputSimple.forward, deepclr.py:284-287) for the
- * reference architecture only -- five conv layers 259 -> 256 -> 256 -> 512 -> 512 -> 1024, the widths of every shipped
- * model_config.yaml -- with the activations of 16 points per wave kept in registers through all layers and the
- * weights of all layers streamed once per 64-point workgroup through an LDS ring (LDS-DMA). Other widths:
- * DCLR_E_UNSUPPORTED (callers fall back to dclr_head_conv_fused_f16).
- * dclr_head_reg_packed_bytes: size of the packed weight stream.
- * dclr_head_reg_pack: w_host[l] DEVICE pointers to row-major f32 (n[l], k_in[l]) weights, the *_host arrays
- *   themselves HOST arrays; k_in = {259 (or any <= 288), 256, 256, 512, 512}; kmap0: 288 i32 (device): column of
- *   rows E -> reference input column of layer 0, -1 = zero.
- * dclr_head_conv_reg_f16: x rows (m, ldx) with k_in valid leading columns (k_in % 8 == 0, <= 288); bias: the five
- *   layers' biases back to back (2560 floats); colmax (m / rows_per_group, 1024) zero-filled by the caller;
- *   m and rows_per_group multiples of 64. */
-long long dclr_head_reg_packed_bytes(void);
-int dclr_head_reg_pack(int n_layers, const int *k_in_host, const int *n_host, const float *const *w_host,
-                       const int32_t *kmap0, void *packed, dclr_stream_t stream);
-int dclr_head_conv_reg_f16(int m, int k_in, const void *packed, const float *bias, const float *x, int ldx,
-                           float *colmax, int rows_per_group, dclr_stream_t stream);
-
 /* ---- the dense stages of one batch in one call ----------------------------------------------------------
  * Rows F of [templates..., sources...] -> pose outputs y (pairs, n_out): the launches DeepCLR.forward makes
  * after set abstraction (reference: deepclr.py:502-506: merge layers = flow embedding, then the pose head)
@@ -279,8 +260,6 @@ typedef struct DclrMergeArgs {
     float *colmax;                          /* workspace (pairs, head_n[last]) */
     float *fc_tmp[2];                       /* workspace (pairs, max fc width) each */
     float *y;                               /* out (pairs, fc_n[last]) */
-    const void *head_reg_w;                 /* optional: dclr_head_reg_pack stream; with precision 1, npoint % 64 == 0 the */
-    const float *head_reg_bias;             /*   conv chain runs through dclr_head_conv_reg_f16 (NULL: dclr_head_conv_fused_f16) */
 } DclrMergeArgs;
 int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
 

@@ -2,8 +2,10 @@
 
 Follows /root/reference/deepclr/data/transforms/transforms.py: SystematicErasing._systematic_erasing (257-268),
 RangeSelection._range_selection (102-110), TruncateDimension (276-282), composed in the order the shipped data
-configs list them (erase -> range -> truncate). Deterministic, so pinned by reading the code; the reference's
-RandomErasing (113-134) draws from numpy's global generator and has no device counterpart with equal draws.
+configs list them (erase -> range -> truncate). PINNED: tests/golden/preprocess.npz holds outputs of the reference's
+own classes on seeded scans (tests/golden/make_preprocess_golden.py, 11 cases with NaN / inf / boundary / empty
+inputs) and tests/test_oracle.py replays them bit for bit. The reference's RandomErasing (113-134) draws from numpy's
+global generator and has no device counterpart with equal draws.
 """
 import numpy as np
 

@@ -30,7 +30,7 @@ def test_algorithmic_work_matches_the_design_figures(bench):
     assert bound == 'mfma' and flops == 2.0 * rows * (128 * 128 + 128 * 256) + 2.0 * rows * 128 * 5
     assert abs(flops / pairs - 2.01e9) < 0.05e9                       # 2.01 GFLOP per pair (+ layer-1 rest)
     bound, flops, _ = bench.algorithmic_work('head_conv_fused[8x1024]', cfg)
-    assert bound == 'mfma' and abs(flops / pairs - 2.15e9) < 0.02e9    # 1024 x 1,049,344 MAC (+ 5 padded input columns)
+    assert bound == 'mfma' and flops / pairs == 2.0 * 1024 * 1049344      # 1024 x 1,049,344 MAC: K = 259 in layer 1, not the padded 264
     bound, flops, _ = bench.algorithmic_work('linear_pair[2x8192x128x64]', cfg)
     assert bound == 'mfma' and flops == 4.0 * 8192 * 128 * 64
     bound, nbytes, _ = bench.algorithmic_work('knn_rows[8x1024x20]', cfg)
@@ -76,6 +76,48 @@ def test_peaks_and_workload_constants(bench):
     assert (args.group, args.depth, args.steps) == (1, 2, 7)
 
 
+def test_measurement_modes_and_the_whole_groups_rule(bench, capsys):
+    """--strict / --h2d / --clouds ring / --latency beside the headline; with dense groups a timed window that is not a
+    whole number of groups would credit work it did not do: rejected."""
+    args = bench.parse_args(['--strict', '--steps', '7'])
+    assert (args.group, args.dense_group, args.depth, args.steps) == (1, 0, 3, 7)
+    with pytest.raises(SystemExit):
+        bench.parse_args(['--strict', '--group', '4'])
+    for bad in (['--steps', '25', '--warmup', '5'], ['--config', 'c5', '--steps', '30']):
+        with pytest.raises(SystemExit):
+            bench.parse_args(bad)
+        assert 'whole' in capsys.readouterr().err
+    assert bench.parse_args(['--steps', '30']).steps == 30                        # c2: groups of 10
+    assert bench.parse_args(['--steps', '25', '--dense-group', '0']).steps == 25   # no dense groups: any window
+    assert bench.parse_args(['--steps', '25', '--no-overlap']).steps == 25
+    assert bench.parse_args(['--steps', '20', '--warmup', '5']).warmup == 5        # the driver's arguments
+    args = bench.parse_args(['--clouds', 'ring', '--h2d'])
+    assert args.clouds == 'ring' and args.h2d
+    with pytest.raises(SystemExit):
+        bench.parse_args(['--config', 'c4', '--clouds', 'ring'])                   # a LiDAR scan is not a ModelNet object
+    assert bench.parse_args(['--latency', '--steps', '25']).latency                # no group rule: one pair per call
+    with pytest.raises(SystemExit):
+        bench.parse_args(['--latency', '--gpus', '2'])
+
+
+def test_two_real_ranks_end_to_end_on_cpu(tmp_path):
+    """`python bench.py --gpus 2 --cpu-stub`: the launcher starts two real children, each runs run() on gloo with the
+    stand-in compute function -- rank > 0 code, the all-gather bookkeeping, the max-over-ranks timing and rank 0's JSON
+    line are exercised before any multi-GPU hardware is."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    for argv, gathers in ((['--steps', '10', '--warmup', '3', '--strict'], 4),       # 1 (warm-up fence) + 2 full + 1 partial
+                          (['--steps', '8', '--warmup', '0', '--gather-every', '3'], 3)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--cpu-stub'] + argv,
+                             env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1                                                     # rank 0 alone prints
+        line = json.loads(lines[0])
+        assert line['ranks_seen'] == [0, 1] and line['n_gpus'] == 2 and line['gather_check'] is True
+        assert line['collectives']['all_gathers'] == gathers and line['config']['parallelism'] == 'dp2'
+        assert 'stub' in line['data'] and line['scaling'] == 'weak' and line['roofline'] is None
+
+
 def test_launch_timer_samples_per_kind_not_per_step(bench, monkeypatch):
     """Launches that cover several batches (one per `group` steps) must be sampled whatever the warm-up count."""
     class _Ev:
@@ -91,6 +133,8 @@ def test_launch_timer_samples_per_kind_not_per_step(bench, monkeypatch):
     assert t.begin('sa_msg_fused[64x16384]') is not None                      # kinds are counted separately
     every = bench.LaunchTimer()                                               # default: every launch (few, grouped launches)
     assert all(every.begin('fps_clouds[160x16384]') is not None for _ in range(4))
+    every.close()                                                             # no device here: no raw events to destroy
+    assert every._raw_all == []
 
 
 def test_rank_environments_of_the_self_launcher(bench):
@@ -131,8 +175,8 @@ def test_main_becomes_the_launcher_only_without_world_size(bench, monkeypatch):
     monkeypatch.setattr(bench, 'run', lambda args: calls.append(('run', args.gpus)))
     monkeypatch.delenv('WORLD_SIZE', raising=False)
     with pytest.raises(SystemExit) as e:
-        bench.main(['--gpus', '8', '--steps', '5', '--warmup', '1'])
-    assert e.value.code == 0 and calls == [(8, ['--gpus', '8', '--steps', '5', '--warmup', '1'])]
+        bench.main(['--gpus', '8', '--steps', '10', '--warmup', '1'])
+    assert e.value.code == 0 and calls == [(8, ['--gpus', '8', '--steps', '10', '--warmup', '1'])]
     monkeypatch.setenv('WORLD_SIZE', '8')                  # under torch.distributed.run: a rank, not a launcher
     bench.main(['--gpus', '8'])
     assert calls[-1] == ('run', 8)

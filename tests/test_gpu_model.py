@@ -394,25 +394,17 @@ def test_fused_head_chain_equals_layer_by_layer_kernels(monkeypatch):
     _close(split, want.float())
     err32, err16 = (fused.double().cpu() - want).abs().max().item(), (split.double().cpu() - want).abs().max().item()
     assert err16 <= 2 * err32 + 1e-7, (err16, err32)        # no less accurate than the f32 matrix instructions
-    # the register-resident chain (activations in registers, weights through the LDS ring; opt-in): same operator
-    monkeypatch.setenv('DCLR_HEAD_REG', '1')
-    assert head._use_reg(rows, pairs) and not head._use_reg(rows, 128)          # 32 rows per group: falls back
-    packed, bias = head._packed_reg()
-    reg = ops.head_conv_reg_f16(e, ops.E_STRIDE, packed, bias, pairs)
-    _close(reg, want.float())
-    err_reg = (reg.double().cpu() - want).abs().max().item()
-    print('head chain max abs error vs float64: f32 MFMA %.3g, split-f16 LDS form %.3g, split-f16 register form %.3g'
-          % (err32, err16, err_reg))
-    assert err_reg <= 2 * err32 + 1e-7, (err_reg, err32)
-    # every group size and row count the model can hand it: per-pair groups of 64 .. 1024 rows, ragged last workgroup wave
+    print('head chain max abs error vs float64: f32 MFMA %.3g, split-f16 %.3g' % (err32, err16))
+    # every group size and row count the model can hand it: per-pair groups of 64 .. 1024 rows
     for rows2, pairs2 in ((64, 1), (128, 2), (1024, 1), (1536, 3), (8192, 8)):
         e2 = e[:rows2].contiguous() if rows2 <= rows else torch.cat((e, e.flip(0)))[:rows2].contiguous()
-        a = ops.head_conv_reg_f16(e2, ops.E_STRIDE, packed, bias, pairs2)
-        b = ops.head_conv_fused_f16(e2, ops.E_STRIDE, head._packed_f16(), pairs2)
-        _close(a, b.cpu())
-        assert torch.equal(a, ops.head_conv_reg_f16(e2, ops.E_STRIDE, packed, bias, pairs2))     # deterministic
-    with pytest.raises(RuntimeError):
-        ops.head_conv_reg_f16(e[:96].contiguous(), ops.E_STRIDE, packed, bias, 1)                 # m % 64 != 0
+        a = ops.head_conv_fused_f16(e2, ops.E_STRIDE, head._packed_f16(), pairs2)
+        assert torch.equal(a, ops.head_conv_fused_f16(e2, ops.E_STRIDE, head._packed_f16(), pairs2))     # deterministic
+        want2 = e2[:, :259].double().cpu()
+        want2 = torch.cat((want2[:, 256:259], want2[:, :256]), dim=1)
+        for w, bias in head.conv.affine_params():
+            want2 = torch.relu(want2 @ w.detach().double().cpu().reshape(w.shape[0], -1).t() + bias.detach().double().cpu())
+        _close(a, want2.view(pairs2, rows2 // pairs2, -1).max(dim=1).values.float())
 
 
 def test_full_size_kitti_batch_properties_and_oracle_pair():
@@ -565,6 +557,102 @@ def test_pipelined_runner_matches_plain_forward():
                          out=torch.zeros(3, 8, device=DEV))
 
 
+def test_pipelined_runner_with_inputs_ready_and_buffer_ring_reuse():
+    """inputs_ready=True (what bench.py times): sampling launches do not wait for the caller's stream, so the prep ring
+    (3 slots per plan and stream) is ordered by its release events alone. Twelve distinct batches = at least five launches
+    per stream and plan, with and without dense groups: every slot is reused, results must equal the plain forward."""
+    from deepclr_amd.pipeline import PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=21))
+    batches = [torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=7 * i)).to(DEV) for i in range(12)]
+    with torch.no_grad():
+        want = [model(b)[0] for b in batches]
+    torch.cuda.synchronize()
+    for depth, group, dense in ((1, 1, False), (2, 1, False), (1, 2, True), (2, 2, True), (3, 2, False)):
+        runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense, inputs_ready=True)
+        got = list(runner.run(batches))
+        assert len(got) == len(want)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (depth, group, dense, i)
+
+
+def test_pipelined_run_prefetches_every_batch_after_the_first(monkeypatch):
+    """run() must hand every batch but the first to a side stream (the slice of upcoming batches skipped one
+    per window, which was then sampled synchronously on the main stream)."""
+    from deepclr_amd.pipeline import PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=22))
+    batches = [torch.from_numpy(synthetic.make_batch('kitti', 1, 2048, first_pair=3 * i)).to(DEV) for i in range(10)]
+    main = torch.cuda.current_stream().cuda_stream
+    on_main = []
+    real = type(model).cloud_feature_rows
+    monkeypatch.setattr(type(model), 'cloud_feature_rows',
+                        lambda self, x, sample=None: on_main.append(torch.cuda.current_stream().cuda_stream == main)
+                        or real(self, x, sample))
+    for depth, group, dense in ((2, 1, False), (3, 1, False), (2, 2, False), (2, 2, True)):
+        on_main.clear()
+        runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense)
+        assert len(list(runner.run(batches))) == len(batches)
+        assert not any(on_main), (depth, group, dense, on_main)          # every set-abstraction pass ran on a side stream
+
+
+def test_host_batch_feeder_matches_resident_batches():
+    """--h2d path of bench.py: batches in pinned host memory, copied on a copy stream into a ring of device buffers that
+    is shorter than the stream of batches (every slot rewritten several times while older batches are still in flight)."""
+    from deepclr_amd.pipeline import HostBatchFeeder, PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=23))
+    host = [torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=5 * i)).pin_memory() for i in range(14)]
+    with torch.no_grad():
+        want = [model(h.to(DEV))[0] for h in host]
+    torch.cuda.synchronize()
+    for depth, group, dense in ((2, 1, False), (2, 2, True), (1, 3, True)):
+        runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense, inputs_ready=True)
+        feeder = HostBatchFeeder(runner, host[0].to(DEV))
+        ahead = depth * group
+        feeder.fill(host[:ahead])
+        got = []
+        for i in range(len(host)):
+            nxt = host[i + ahead] if i + ahead < len(host) else None
+            got.append(feeder.step(nxt).clone())
+        assert feeder.bytes_copied == len(host) * host[0].numel() * 4
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (depth, group, dense, i)
+
+
+def test_ring_scan_clouds_reach_the_ball_query_caps_and_match_the_oracle():
+    """LiDAR-density clouds (deepclr_amd/synthetic.py:ring_scan, bench.py --clouds ring): near the sensor a 1 m ball holds
+    more than nsample = 1024 points, so set abstraction takes its overflow path (roll back, exhaustive in-order sweep).
+    Counts exact, features and poses against the oracle."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=4)
+    model, orc = _models(cfg, sd)
+    x_np = synthetic.make_batch('ring', 1, 16384, first_pair=2)
+    x = torch.from_numpy(x_np).to(DEV)
+    sa = model._cloud_layers[0]._sa0
+    fps, gpts, gbox = ops.fps_clouds_grouped(x, 1024)
+    xyz = torch.from_numpy(x_np[:, :, :3]).contiguous()
+    fps_o = oracle.furthest_point_sample(xyz, 1024)
+    assert torch.equal(fps.cpu(), fps_o)
+    rows, counts = ops.sa_msg_fused(x, fps, sa.radii, sa.nsamples, sa.packed_mlps(), want_counts=True, groups=(gpts, gbox))
+    new_xyz = torch.gather(xyz, 1, fps_o.long()[:, :, None].expand(-1, -1, 3))
+    capped = 0
+    for s, (r, ns) in enumerate(zip(sa.radii, sa.nsamples)):
+        bq = oracle.ball_query(r, ns, xyz, new_xyz)
+        hits = 1 + (bq[:, :, 1:] != bq[:, :, :1]).sum(-1)
+        assert torch.equal(counts[:, :, s].cpu(), hits.to(torch.int32))
+        capped += int((hits == ns).sum())
+    assert capped > 0                                               # the caps ARE reached (Gaussian bench clouds: never)
+    print('ring clouds: %d of %d (centroid, scale) neighbourhoods at their nsample cap; mean hits %.1f / %.1f'
+          % (capped, 2 * 2 * 1024, float(counts[:, :, 0].float().mean()), float(counts[:, :, 1].float().mean())))
+    with torch.no_grad():
+        feat = model.cloud_features(x.clone())
+        y, _, _ = model(x.clone())
+    _close(feat, orc.cloud_features(torch.from_numpy(x_np)), stage='ring clouds: cloud_features vs oracle')
+    y_o = orc(torch.from_numpy(x_np))
+    assert np.abs(_mats(y) - _mats(y_o)).max() < 1e-4
+
+
 def test_sequence_mode_computes_each_frame_once_and_matches_pairwise_calls():
     """Reference sequential mode (models/base.py:97-112): frame t is the source of pair (t-1, t) and the template
     of pair (t, t+1). The chunked runner must return exactly what per-frame predict() calls return."""
@@ -668,19 +756,34 @@ def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_orac
 
 def test_split_f16_range_guard(monkeypatch):
     """The default matrix path carries operands as f16 hi/lo halves and clamps at +-65504 (csrc/mma16f.h). Weights out
-    of range are refused when they are packed; activations out of range are caught by the checked mode
-    (ops.CHECK_RANGE / DCLR_CHECK_RANGE=1), which reruns the dense stages on the f32 matrix instructions; and the f32
-    path itself (DCLR_PRECISION=f32) still agrees with the oracle on such a checkpoint."""
+    of range are refused when they are packed. Activations out of range are caught by the checked forward, which reruns
+    the dense stages on the f32 matrix instructions: by DEFAULT on the first forward after the weights changed
+    (ops.CHECK_RANGE = 'first'), on every forward with 'always', never with 'never'; and the f32 path itself
+    (DCLR_PRECISION=f32) still agrees with the oracle on such a checkpoint."""
+    assert ops.CHECK_RANGE == 'first'                                                      # the shipped default
     cfg = synthetic.model_cfg('kitti')
     sd = synthetic.random_state_dict(cfg, seed=9)
     x_cpu = torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=90))
-    # in range: the checked mode passes and returns exactly what the unchecked forward returns
+    # in range: the first forward is a checked one and passes; later ones go straight through, with identical results
     model, orc = _models(cfg, sd)
+    calls = []
+    real = type(model)._merge_rows_checked
+    monkeypatch.setattr(type(model), '_merge_rows_checked', lambda self, *a: calls.append(1) or real(self, *a))
     with torch.no_grad():
+        assert model._range_unchecked()
+        y_first, _, _ = model(x_cpu.to(DEV))
+        assert calls == [1] and not model._range_unchecked()
         y_plain, _, _ = model(x_cpu.to(DEV))
-        monkeypatch.setattr(ops, 'CHECK_RANGE', True)
+        assert calls == [1]                                                                # not checked again
+        monkeypatch.setattr(ops, 'CHECK_RANGE', 'always')
         y_checked, _, _ = model(x_cpu.to(DEV))
-        monkeypatch.setattr(ops, 'CHECK_RANGE', False)
+        assert calls == [1, 1]
+        monkeypatch.setattr(ops, 'CHECK_RANGE', 'first')
+        model.load_state_dict(sd)                                                          # weights rewritten: checked once more
+        assert model._range_unchecked()
+        model(x_cpu.to(DEV))
+        assert calls == [1, 1, 1] and not model._range_unchecked()
+    _close(y_first, y_plain.cpu(), stage='first (checked) forward vs plain forward (in range)')
     _close(y_checked, y_plain.cpu(), stage='checked mode vs plain forward (in range)')
     # activations out of range: the last flow-embedding layer scaled so that rows E reach ~1e6
     big = {k: v.clone() for k, v in sd.items()}
@@ -689,12 +792,14 @@ def test_split_f16_range_guard(monkeypatch):
     model_big, orc_big = _models(cfg, big)
     y_o = orc_big(x_cpu)
     with torch.no_grad():
-        y16, _, _ = model_big(x_cpu.to(DEV))                                               # silently clamped ...
-        assert float((y16.cpu() - y_o).abs().max()) > 1e-3                                 # ... and therefore wrong
-        monkeypatch.setattr(ops, 'CHECK_RANGE', True)
-        with pytest.raises(RuntimeError, match='split-f16 matrix path out of range'):
+        with pytest.raises(RuntimeError, match='split-f16 matrix path out of range'):      # the default: first use raises
             model_big(x_cpu.to(DEV))
-        monkeypatch.setattr(ops, 'CHECK_RANGE', False)
+        with pytest.raises(RuntimeError, match='split-f16 matrix path out of range'):      # and keeps raising: never passed
+            model_big(x_cpu.to(DEV))
+        monkeypatch.setattr(ops, 'CHECK_RANGE', 'never')
+        y16, _, _ = model_big(x_cpu.to(DEV))                                               # unchecked: silently clamped ...
+        assert float((y16.cpu() - y_o).abs().max()) > 1e-3                                 # ... and therefore wrong
+        monkeypatch.setattr(ops, 'CHECK_RANGE', 'first')
         monkeypatch.setattr(ops, 'PRECISION', 'f32')
         y32, _, _ = model_big(x_cpu.to(DEV))
     _close(y32, y_o, stage='f32 matrix path vs oracle, activations ~1e6')

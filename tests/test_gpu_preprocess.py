@@ -39,6 +39,30 @@ def test_prepare_cloud_matches_reference_transforms(n, c, kw):
     assert np.array_equal(got, want, equal_nan=True)
 
 
+def _golden_cases():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'preprocess.npz'))
+    for name in sorted({k.split('/')[0] for k in g.files}):
+        nth, start, lo, hi, dim = g[name + '/params']
+        kw = dict(nth=int(nth), start=int(start), min_range=float(lo), max_range=float(hi))
+        if dim >= 0:
+            kw['input_dim'] = int(dim)
+        yield name, g[name + '/raw'], g[name + '/want'], kw
+
+
+def test_prepare_cloud_matches_vectors_written_by_the_reference_transforms():
+    """tests/golden/preprocess.npz: outputs of the reference's own TruncateDimension / SystematicErasing / RangeSelection
+    (tests/golden/make_preprocess_golden.py ran /root/reference/deepclr/data/transforms/transforms.py) -- NaN, +inf,
+    boundary values, empty and single-point results included. Bit-exact, same row order."""
+    seen = 0
+    for name, raw, want, kw in _golden_cases():
+        got = preprocess.prepare_cloud(torch.from_numpy(raw).to(DEV), **kw).cpu().numpy()
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        assert np.array_equal(got, want, equal_nan=True), name
+        seen += 1
+    assert seen == 11
+
+
 def test_subsample_is_a_subset_without_repeats_and_rejects_bad_input():
     raw = torch.from_numpy(_scan(30000, 4, 1)).to(DEV)
     g = torch.Generator(device=DEV)

@@ -136,6 +136,24 @@ def test_synthetic_inputs_are_deterministic():
     assert m.shape == (2, 64, 3) and np.abs(m).max() < 1.5
 
 
+def test_ring_scan_clouds_have_lidar_density():
+    """bench.py --clouds ring: 64 rings x azimuth, every second point kept, exactly n points in scan order; near the sensor a
+    1 m ball holds hundreds of points (the Gaussian clouds: ~20), so ball queries reach the nsample caps 512 / 1024."""
+    from scipy.spatial import cKDTree
+    r = synthetic.make_batch('ring', 1, 16384)
+    assert r.shape == (2, 16384, 4) and r.dtype == np.float32 and np.isfinite(r).all()
+    assert np.array_equal(r, synthetic.make_batch('ring', 1, 16384))
+    t = r[0]
+    rng_xy = np.linalg.norm(t[:, :2], axis=1)
+    assert rng_xy.min() > 1.0 and np.linalg.norm(t[:, :3], axis=1).max() < 81.0 and 0.0 <= t[:, 3].min() and t[:, 3].max() <= 1.0
+    counts = cKDTree(t[:, :3]).query_ball_point(t[::8, :3], 1.0, return_length=True)
+    g = synthetic.make_batch('kitti', 1, 16384)[0]
+    counts_g = cKDTree(g[:, :3]).query_ball_point(g[::8, :3], 1.0, return_length=True)
+    assert counts.max() >= 1024 and counts.mean() > 10 * counts_g.mean() and counts_g.max() < 512
+    big = synthetic.make_batch('ring', 1, 65536)[0]
+    assert big.shape == (65536, 4)
+
+
 def test_reference_import_names_resolve_to_this_package(tmp_path):
     """What scripts/inference.py:9-13 and scripts/timing.py:6-10 import must exist under the reference's names."""
     import deepclr_amd.models

@@ -1,5 +1,7 @@
 """CPU tests: the oracle against the committed goldens (reference composition run in the build
 container, tests/golden/make_golden.py) and against independent restatements of its primitives."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -113,3 +115,19 @@ def test_dual_quat_roundtrip():
     label = lt.from_matrix(m)
     assert np.abs(lt.to_matrix(label) - m).max() < 1e-7   # _dqnormalize adds eps=1e-8 to the norm
     assert np.abs(olabels.dual_quat_to_matrix(label) - m).max() < 1e-7
+
+
+def test_preprocess_oracle_reproduces_the_reference_transform_outputs(golden_dir):
+    """tests/golden/preprocess.npz was written by the reference's own transforms.py (make_preprocess_golden.py):
+    the numpy restatement the GPU preparation kernel is checked against must reproduce every case bit for bit."""
+    from oracle import preprocess as opre
+    g = np.load(os.path.join(golden_dir, 'preprocess.npz'))
+    names = sorted({k.split('/')[0] for k in g.files})
+    assert len(names) == 11
+    for name in names:
+        nth, start, lo, hi, dim = g[name + '/params']
+        kw = dict(nth=int(nth), start=int(start), min_range=float(lo), max_range=float(hi))
+        if dim >= 0:
+            kw['input_dim'] = int(dim)
+        got = opre.prepare_cloud(g[name + '/raw'], **kw)
+        assert got.shape == g[name + '/want'].shape and np.array_equal(got, g[name + '/want'], equal_nan=True), name
