@@ -604,8 +604,6 @@ def run(args):
     if not stub:
         x_host = torch.from_numpy(synthetic.make_batch(cloud_kind, pairs_cfg, points, first_pair=rank * pairs_cfg))
         x = x_host.to(dev)
-        if args.h2d:
-            x_host = x_host.pin_memory()
 
     pairs_per_step = pairs_cfg
     feeder = None
@@ -626,8 +624,12 @@ def run(args):
     if args.h2d:
         if runner is None or args.sequence:
             raise SystemExit('bench.py: --h2d runs through the pipelined runner')
+        # the loader's side: chunks of consecutive batches in pinned memory (here: the same batch, `chunk` times)
         feeder = HostBatchFeeder(runner, x)
-        feeder.fill([x_host] * (args.depth * args.group))
+        host_chunk = torch.stack([x_host] * feeder.chunk).pin_memory()
+        while feeder.pending() < args.depth * args.group and feeder.room():
+            feeder.feed(host_chunk)
+        feeder.fill()
     elif runner is not None:
         for _ in range(args.depth * args.group):
             runner.prefetch(x, flush=False)
@@ -649,7 +651,9 @@ def run(args):
         # or the slots of a whole dense group at its first step
         out = None
         if feeder is not None:
-            y = feeder.step(x_host)
+            if feeder.room() and feeder.pending() <= args.depth * args.group:
+                feeder.feed(host_chunk)                        # one copy per `chunk` steps, on the copy stream
+            y = feeder.step()
         elif runner is not None:
             if gather is not None and not args.sequence:
                 span = runner.group_start(x)
@@ -830,7 +834,8 @@ def run(args):
                                    + '; {} architecture, seeded random weights'.format(
                                        'kitti_00-06' if kind == 'kitti' else 'modelnet40'),
                        'id': args.config, 'mode': mode, 'clouds': args.clouds,
-                       'input': 'pinned host memory, copied every step inside the loop' if args.h2d else 'resident in HBM',
+                       'input': ('pinned host memory, copied inside the loop in chunks of {} batches'.format(feeder.chunk)
+                                 if args.h2d else 'resident in HBM'),
                        'pairs_per_gpu': pairs_per_step, 'points_per_cloud': points,
                        'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
@@ -845,7 +850,8 @@ def run(args):
         }
         if feeder is not None:
             copied = feeder.bytes_copied - copied0
-            result['h2d'] = {'bytes_per_step': copied / args.steps, 'gb_per_s': copied / elapsed / 1e9}
+            result['h2d'] = {'bytes_per_step': copied / args.steps, 'gb_per_s': copied / elapsed / 1e9,
+                             'batches_per_copy': feeder.chunk}
         if gather_check is not None:
             result['gather_check'] = gather_check
         if roofline_sampler is not None:

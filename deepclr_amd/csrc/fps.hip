@@ -308,6 +308,10 @@ __device__ unsigned long long fps_dbg[16];     // [0] active (wave, round) count
 #define FPS_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
 #endif
 
+#ifndef FPS_J
+#define FPS_J 3           // samples a barrier round may accept (register kernel; the workspace kernel keeps 3)
+#endif
+
 struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
     int32_t k;
     float x, y, z;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     __shared__ FpsCand cand[2][16];                        // per-wave candidate payload, by round parity
     __shared__ unsigned long long wpk[2][16];              // MULTI: per-wave packed candidate, by round parity
     __shared__ uint32_t wru[2][16];                        // MULTI: per-wave runner-up (largest other running minimum)
-    __shared__ float plist[4][4];                          // MULTI: the samples accepted for the next round
+    __shared__ float plist[FPS_J][4];                      // MULTI: the samples accepted for the next round
     __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         // p3 after p1, p2, and so on. All waves evaluate the test on the same 16 published entries, so they agree
         // without another exchange; then each applies the accepted samples one after the other. The exchange
         // (select, publish, barrier, combine) -- two thirds of a round -- is paid once per batch of samples.
-        constexpr int J = 3;
+        constexpr int J = FPS_J;
         if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
         __syncthreads();
         float pcx[J] = {cx}, pcy[J] = {cy}, pcz[J] = {cz};

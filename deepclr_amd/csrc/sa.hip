@@ -22,12 +22,13 @@
 //           of the distance, as in fps.hip) and scans only the groups its largest ball can reach --
 //           a dozen 64-point slices instead of N/64. Hits then arrive out of index order, which is
 //           irrelevant while a neighbourhood stays within its nsample cap (the max does not care);
-//           a centroid whose count exceeds a cap is left to the exhaustive in-order sweep, which the
-//           workgroup runs only if one of its waves needs it.
+//           a centroid whose count exceeds a cap (or the ring) is redone wave-locally: a radix select over the
+//           hits of its candidate groups finds the nsample-th smallest point index, which is all the index order
+//           decides. The exhaustive in-order sweep serves calls without groups only.
 // Slots that would only repeat the first hit are skipped: max() over a multiset equals max() over
 // its support, so the result is identical. A centroid with no hit reproduces the published
 // behaviour (zero-filled index row => every slot is point 0).
-#include "mma.h"
+#include "mma16f.h"
 
 namespace {
 
@@ -92,7 +93,15 @@ __shared__ unsigned long long sa_dbg_l[4][2];
 // fragments (A operand, lane (m, kq) holds W[m][4 kq .. 4 kq + 3]) are laid out for that k order.
 // 52 MFMAs per pass; the scalar version (lane = entry, 832 FMAs with LDS-broadcast weights) took ~20k
 // cycles per pass and dominated the kernel wherever neighbourhoods are dense.
-template <int C>
+//
+// F16: layers 2 and 3 (K = 16: one k-step of v_mfma_f32_16x16x16_f16, whose operand maps are the f32 form's with
+// four consecutive k per lane -- lane (e, kq) holds k = 4 kq .. 4 kq + 3 -- so the accumulator of one layer is
+// still the B operand of the next) run on split-f16 operands (mma16f.h: hi*hi + 2^-11 (hi*lo + lo*hi), f32
+// accumulation, f32-grade results): 3 + 6 f16 instructions instead of 4 + 8 f32 ones at a quarter of the matrix-pipe
+// time each. With dense neighbourhoods (LiDAR near field, ModelNet) four waves per SIMD queue on one matrix pipe and
+// the drain was bound by it (1,470 cycles per 16-entry tile against 416 of pipe time). Layer 1 (K = 3 or 4) stays on
+// the f32 instruction: one issue either way.
+template <int C, bool F16>
 __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int head, int take) {
     cloud = dclr_uniform(cloud);
     wave = dclr_uniform(wave); s = dclr_uniform(s); head = dclr_uniform(head); take = dclr_uniform(take);
@@ -130,6 +139,20 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         c1[j] = b1[4 * kq + j]; c2[j] = b2[4 * kq + j];
         c3[0][j] = b3[4 * kq + j]; c3[1][j] = b3[16 + 4 * kq + j];
     }
+    // split-f16 weight fragments (unused and dropped by the compiler in the f32 instance)
+    dclr_h4 a2h, a2l, a3h[2], a3l[2];
+    if constexpr (F16) {
+        auto split4 = [](const float (&v)[4], dclr_h4 &hi, dclr_h4 &lo) {
+            dclr_h2 h0, l0, h1, l1;
+            dclr_split2(v[0], v[1], h0, l0);
+            dclr_split2(v[2], v[3], h1, l1);
+            hi = dclr_h4{h0[0], h0[1], h1[0], h1[1]};
+            lo = dclr_h4{l0[0], l0[1], l1[0], l1[1]};
+        };
+        split4(a2, a2h, a2l);
+        split4(a3[0], a3h[0], a3l[0]);
+        split4(a3[1], a3h[1], a3l[1]);
+    }
     uint32_t *acc = &sa_acc[wave][s][0][0];
 #ifdef SA_DEBUG
     SA_STAMP(g2);
@@ -139,17 +162,42 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         const float x = stg[4 * (16 * t + e16) + kq];                        // input component kq of entry 16 t + e16
         dclr_f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
         h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x, h1, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h1[i] = fmaxf(h1[i] + c1[i], 0.f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) h2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], h1[j], h2, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h2[i] = fmaxf(h2[i] + c2[i], 0.f);
         dclr_f32x4 h3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (F16) {
+            // relu(h1 + b1) as hi / lo halves = the B operand of layer 2 (k = 4 kq + i)
+            dclr_h2 p0, q0, p1, q1;
+            dclr_split2_relu(h1[0] + c1[0], h1[1] + c1[1], p0, q0);
+            dclr_split2_relu(h1[2] + c1[2], h1[3] + c1[3], p1, q1);
+            const dclr_h4 b1h = {p0[0], p0[1], p1[0], p1[1]}, b1l = {q0[0], q0[1], q1[0], q1[1]};
+            dclr_f32x4 x2 = {0.f, 0.f, 0.f, 0.f};
+            h2 = dclr_f32x4{c2[0], c2[1], c2[2], c2[3]};                     // the accumulator starts at the bias
+            h2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2h, b1h, h2, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2h, b1l, x2, 0, 0, 0);
+            x2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2l, b1h, x2, 0, 0, 0);
+            dclr_split2_relu(fmaf(x2[0], DCLR_SPLIT_INV, h2[0]), fmaf(x2[1], DCLR_SPLIT_INV, h2[1]), p0, q0);
+            dclr_split2_relu(fmaf(x2[2], DCLR_SPLIT_INV, h2[2]), fmaf(x2[3], DCLR_SPLIT_INV, h2[3]), p1, q1);
+            const dclr_h4 b2h = {p0[0], p0[1], p1[0], p1[1]}, b2l = {q0[0], q0[1], q1[0], q1[1]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[0][j], h2[j], h3[0], 0, 0, 0);
-            h3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[1][j], h2[j], h3[1], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                dclr_f32x4 x3 = {0.f, 0.f, 0.f, 0.f};
+                h3[u] = __builtin_amdgcn_mfma_f32_16x16x16f16(a3h[u], b2h, h3[u], 0, 0, 0);
+                x3 = __builtin_amdgcn_mfma_f32_16x16x16f16(a3h[u], b2l, x3, 0, 0, 0);
+                x3 = __builtin_amdgcn_mfma_f32_16x16x16f16(a3l[u], b2h, x3, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h3[u][i] = fmaf(x3[i], DCLR_SPLIT_INV, h3[u][i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h1[i] = fmaxf(h1[i] + c1[i], 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[j], h1[j], h2, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h2[i] = fmaxf(h2[i] + c2[i], 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h3[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[0][j], h2[j], h3[0], 0, 0, 0);
+                h3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[1][j], h2[j], h3[1], 0, 0, 0);
+            }
         }
         const int cen = tag[16 * t + e16];
         const int cen0 = __builtin_amdgcn_readfirstlane(cen);
@@ -193,7 +241,7 @@ __device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz
 }
 
 
-template <int C, int NCH>
+template <int C, int NCH, bool F16>
 __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                                                                const float *__restrict__ clouds,
                                                                const int32_t *__restrict__ fps_idx,
@@ -248,7 +296,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 unsigned long long d0, d1;
                 SA_STAMP(d0);
 #endif
-                sa_drain<C>(cloud, wave, s, qhead[s], take);
+                sa_drain<C, F16>(cloud, wave, s, qhead[s], take);
 #ifdef SA_DEBUG
                 SA_STAMP(d1);
                 t_drain += d1 - d0; n_drain += 1;
@@ -263,7 +311,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
     // Runtime loop over the wave's centroids (coordinates and counts through LDS) to keep one small
     // copy of the code; `done` bit c = centroid slot c is finished, its true counts are in sa_tot.
     uint32_t done = 0;
-    bool need_sweep = prm.group_pts == nullptr;
+    const bool need_sweep = prm.group_pts == nullptr;
     if (prm.group_pts != nullptr) {
         const float4 *gp = prm.group_pts + bi * (size_t)prm.n_groups * prm.group_size;
         // lane g owns the boxes of groups g, 64 + g, ... (NCH chunks of 64 groups: 1 for the register sampler's <= 64
@@ -350,9 +398,94 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 }
             }
             if (over || n1[0] > prm.nsample[0] || (prm.n_scales > 1 && n1[1] > prm.nsample[1])) {
+                // Crowded centroid: the ring would overflow (> ~450 neighbours) or a cap is exceeded, and then INDEX order
+                // decides which nsample neighbours count. Take its entries back (none has been drained) and redo it on
+                // the same candidate groups -- they hold every hit, in any order:
+                //   1. exact hit counts per scale (known already unless the pass above stopped early);
+                //   2. per scale over its cap: the nsample-th smallest point index T among its hits, by a two-level
+                //      radix select on the 16-bit index (256-bin histograms in this wave's drain staging buffer);
+                //   3. stage the hits with index <= T, draining whenever the ring fills (their membership is final).
+                // Rare (LiDAR near field), wave-local and exact; the exhaustive in-order sweep below is left to calls
+                // without groups. Before: one such centroid sent its whole workgroup through all N points.
                 qn[0] = q0[0]; qn[1] = q0[1];
-                need_sweep = true;
-                continue;
+                auto scan = [&](auto &&per_slice) {
+#pragma unroll 1
+                    for (int chn = 0; chn < NCH; ++chn) {
+#pragma unroll 1
+                        for (uint64_t mm = gm[chn]; mm != 0; mm &= mm - 1) {
+                            const float4 *pg = gp + (size_t)(chn * 64 + __builtin_ctzll(mm)) * prm.group_size + lane;
+#pragma unroll 1
+                            for (int it = 0; it < slices; ++it) {
+                                const float4 qq = pg[it * 64];
+                                const float d2 = dclr_sqdist(cx, cy, cz, qq.x, qq.y, qq.z);
+                                if (__ballot(d2 < prm.radius2_max) == 0) continue;
+                                per_slice(d2, __float_as_uint(qq.w) & 0xFFFFu);
+                            }
+                        }
+                    }
+                };
+                if (over) {
+                    n1[0] = n1[1] = 0;
+                    scan([&](float d2, uint32_t) {
+                        n1[0] += __builtin_popcountll(__ballot(d2 < prm.radius2[0]));
+                        if (prm.n_scales > 1) n1[1] += __builtin_popcountll(__ballot(d2 < prm.radius2[1]));
+                    });
+                }
+                uint32_t thr[SA_MAX_SCALES] = {0xFFFFu, 0xFFFFu};
+                uint32_t *hist = reinterpret_cast<uint32_t *>(sa_obuf[wave]);          // 256 bins (320 words available)
+#pragma unroll 1
+                for (int s = 0; s < prm.n_scales; ++s) {
+                    if (n1[s] <= prm.nsample[s]) continue;
+                    uint32_t prefix = 0;                     // high byte of T once known
+                    int need = prm.nsample[s];               // rank of T among the hits still in play (1-based)
+#pragma unroll 1
+                    for (int level = 0; level < 2; ++level) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) hist[4 * lane + u] = 0u;
+                        const float r2 = prm.radius2[s];
+                        scan([&](float d2, uint32_t k) {
+                            const bool in = d2 < r2 && (level == 0 || (k >> 8) == prefix);
+                            if (in) atomicAdd(&hist[level == 0 ? (k >> 8) : (k & 255u)], 1u);
+                        });
+                        // lane l owns bins 4 l .. 4 l + 3; exclusive prefix over the lanes, then inside the lane
+                        uint32_t cb[4], mine = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { cb[u] = hist[4 * lane + u]; mine += cb[u]; }
+                        uint32_t incl = mine;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const uint32_t up = __shfl_up(incl, off);
+                            if (lane >= off) incl += up;
+                        }
+                        const uint32_t excl = incl - mine;
+                        const int wl = __builtin_ctzll(__ballot(excl < (uint32_t)need && (uint32_t)need <= incl));
+                        uint32_t run = excl, bin = 0, before = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (!found && run + cb[u] >= (uint32_t)need) { bin = 4 * lane + u; before = run; found = true; }
+                            run += cb[u];
+                        }
+                        const uint32_t wbin = (uint32_t)__builtin_amdgcn_readlane((int)bin, wl);
+                        need -= (int)__builtin_amdgcn_readlane((int)before, wl);
+                        if (level == 0) prefix = wbin; else thr[s] = (prefix << 8) | wbin;
+                    }
+                    n1[s] = prm.nsample[s];
+                }
+                scan([&](float d2, uint32_t k) {
+#pragma unroll
+                    for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                        if (s >= prm.n_scales) break;
+                        const bool hit = d2 < prm.radius2[s] && k <= thr[s];
+                        const uint64_t mask = __ballot(hit);
+                        if (mask != 0) {
+                            if (qn[s] + 64 > SA_RING) drain_all(false);           // leaves < 64 entries in each ring
+                            const int pre = (int)dclr_lanemask_lt_popc(mask);
+                            if (hit) sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = ((uint32_t)c << 16) | k;
+                            qn[s] += __builtin_popcountll(mask);
+                        }
+                    }
+                });
             }
             if (qn[0] >= 64 || qn[1] >= 64) drain_all(false);
             done |= 1u << c;
@@ -366,8 +499,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
 #ifdef SA_DEBUG
     { unsigned long long t1; SA_STAMP(t1); t_fast = t1 - t_begin; }
 #endif
-    // ---- exhaustive in-order sweep: only if some wave of the workgroup still has open centroids -----
-    if (__syncthreads_or(need_sweep ? 1 : 0)) {
+    // ---- exhaustive in-order sweep: calls without the sampler's groups (n <= 1024 or no grouped kernel) -----
+    if (need_sweep) {                                      // the same for every wave of the grid (a launch argument)
 #ifdef SA_DEBUG
         unsigned long long w0; SA_STAMP(w0);
 #endif
@@ -496,11 +629,9 @@ __global__ __launch_bounds__(256) void channels_to_rows_kernel(int npoint, int n
 
 }  // namespace
 
-extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *clouds,
-                                 const int32_t *fps_idx, int n_scales, const float *radii_host,
-                                 const int *nsamples_host, const float *const *mlp_host_ptrs,
-                                 float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
-                                 dclr_stream_t stream) {
+static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx, int n_scales,
+                     const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs, float *out_rows,
+                     int32_t *counts, const float *group_pts, const float *group_box, dclr_stream_t stream) {
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
@@ -523,13 +654,36 @@ extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *c
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);
     const int nch = prm.n_groups <= 64 ? 1 : prm.n_groups <= 128 ? 2 : 4;      // chunks of 64 group boxes per lane
-#define SA_LAUNCH(C_, NCH_)                                                                                          \
-    hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,    \
+#define SA_LAUNCH(C_, NCH_, F_)                                                                                          \
+    hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_, F_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,    \
                        fps_idx, out_rows, counts)
-    if (c == 4) { if (nch == 1) SA_LAUNCH(4, 1); else if (nch == 2) SA_LAUNCH(4, 2); else SA_LAUNCH(4, 4); }
-    else        { if (nch == 1) SA_LAUNCH(3, 1); else if (nch == 2) SA_LAUNCH(3, 2); else SA_LAUNCH(3, 4); }
+#define SA_LAUNCH_C(C_)                                                                                                  \
+    do {                                                                                                                 \
+        if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true); else if (nch == 2) SA_LAUNCH(C_, 2, true); else SA_LAUNCH(C_, 4, true); }    \
+        else     { if (nch == 1) SA_LAUNCH(C_, 1, false); else if (nch == 2) SA_LAUNCH(C_, 2, false); else SA_LAUNCH(C_, 4, false); } \
+    } while (0)
+    if (c == 4) SA_LAUNCH_C(4); else SA_LAUNCH_C(3);
+#undef SA_LAUNCH_C
 #undef SA_LAUNCH
     return dclr_launch_status();
+}
+
+extern "C" int dclr_sa_msg_fused(int b, int n, int c, int npoint, const float *clouds,
+                                 const int32_t *fps_idx, int n_scales, const float *radii_host,
+                                 const int *nsamples_host, const float *const *mlp_host_ptrs,
+                                 float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
+                                 dclr_stream_t stream) {
+    return sa_launch(false, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
+                     counts, group_pts, group_box, stream);
+}
+
+extern "C" int dclr_sa_msg_fused_f16(int b, int n, int c, int npoint, const float *clouds,
+                                     const int32_t *fps_idx, int n_scales, const float *radii_host,
+                                     const int *nsamples_host, const float *const *mlp_host_ptrs,
+                                     float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
+                                     dclr_stream_t stream) {
+    return sa_launch(true, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
+                     counts, group_pts, group_box, stream);
 }
 
 extern "C" int dclr_rows_to_channels(int b, int npoint, int nfeat, int xyz_col, int stride, const float *rows,

@@ -199,9 +199,10 @@ def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor])
 
 
 def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[float], nsamples: Sequence[int],
-                 mlps: List[torch.Tensor], want_counts: bool = False, groups=None):
+                 mlps: List[torch.Tensor], want_counts: bool = False, groups=None, precision: Optional[str] = None):
     """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)].
-    groups: (group_pts, group_box) from fps_clouds_grouped for the same clouds, or None."""
+    groups: (group_pts, group_box) from fps_clouds_grouped for the same clouds, or None.
+    precision: 'f16x2' (layers 2, 3 of the shared MLP on split-f16 operands) or 'f32'; default ops.PRECISION."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
     npoint = fps_idx.shape[1]
@@ -211,7 +212,8 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
-    _call('dclr_sa_msg_fused', 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
+    entry = 'dclr_sa_msg_fused_f16' if (precision or PRECISION) == 'f16x2' else 'dclr_sa_msg_fused'
+    _call(entry, 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
                                            ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
                                            ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
           None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),

@@ -265,54 +265,76 @@ class PipelinedSequence(PipelinedForward):
 
 
 class HostBatchFeeder:
-    """Batches that live in (pinned) HOST memory, copied to the device inside the loop on a copy stream of their own, so
-    that the transfer of batch i + depth * group overlaps the kernels of batch i -- what the reference does per pair with
-    a blocking `.cuda()` (/root/reference/scripts/inference.py:89-90). A ring of device buffers receives the copies;
-    a buffer is rewritten only after the step that consumed its previous contents has been enqueued (an event on the
-    caller's stream, which by then has waited for the sampling launch that read the buffer). The sampling launch of a
-    batch waits for the event recorded behind its copy (PipelinedForward.prefetch(ready=...))."""
+    """Batches that live in pinned HOST memory, copied to the device inside the loop on a copy stream of their own, so that
+    the transfer of later batches overlaps the kernels of the current one -- what the reference does per pair with a
+    blocking `.cuda()` (/root/reference/scripts/inference.py:89-90).
 
-    def __init__(self, runner: PipelinedForward, example: torch.Tensor, slots: Optional[int] = None):
+    Copies are made per CHUNK of `chunk` consecutive batches, (chunk, 2B, N, C) contiguous in pinned memory (a loader
+    filling a pinned ring produces exactly that): on this stack a 4 MB pinned copy takes a slow path (9.9 GB/s and 0.34 ms
+    of host time per call, scratch/h2d_probe.py) while 16 MB and more run at 53-55 GB/s on the DMA engines with 2-5 us per
+    enqueue and no compute unit involved. A ring of device chunk buffers receives the copies; a buffer is rewritten only
+    after the steps that consumed its batches have been enqueued (an event on the caller's stream, which by then has waited
+    for the sampling launches that read it). The sampling launch of a batch waits for the event recorded behind its
+    chunk's copy (PipelinedForward.prefetch(ready=...))."""
+
+    def __init__(self, runner: PipelinedForward, example: torch.Tensor, chunk: Optional[int] = None,
+                 slots: Optional[int] = None):
         self._runner = runner
-        n = slots if slots is not None else runner.depth * runner.group + runner.group + 2
-        self._ring = [torch.empty_like(example, device=torch.cuda.current_device()) for _ in range(n)]
-        self._free_after = [None] * n               # event: previous contents consumed
+        self.chunk = chunk if chunk is not None else max(runner.group, 4)
+        ahead = runner.depth * runner.group + runner.group
+        n = slots if slots is not None else -(-ahead // self.chunk) + 2
+        shape = (self.chunk,) + tuple(example.shape)
+        self._ring = [torch.empty(shape, dtype=example.dtype, device=example.device) for _ in range(n)]
+        self._free_after = [None] * n               # event: every batch of the slot's previous contents consumed
+        self._left = [0] * n                        # batches of the slot not yet stepped
         self._copy = torch.cuda.Stream()
         self._next = 0
-        self._queue: Deque[Tuple[int, torch.Tensor]] = deque()     # copied (or copying), not yet stepped: (slot, tensor)
+        self._queue: Deque[Tuple[int, torch.Tensor]] = deque()     # copied (or copying), not yet stepped: (slot, batch view)
         self._offered = 0                           # how many of _queue the runner has taken into prefetch()
         self.bytes_copied = 0
 
-    def _upload(self, host: torch.Tensor) -> None:
+    def room(self) -> bool:
+        """True while another chunk can be uploaded (a ring slot whose batches have all been stepped is free)."""
+        return self._left[self._next] == 0
+
+    def feed(self, host_chunk: torch.Tensor) -> None:
+        """Upload one pinned chunk (k <= chunk batches, (k, 2B, N, C) contiguous) and queue its batches."""
+        if host_chunk.dim() != self._ring[0].dim() or host_chunk.shape[1:] != self._ring[0].shape[1:] \
+                or host_chunk.shape[0] > self.chunk or not host_chunk.is_contiguous():
+            raise RuntimeError("HostBatchFeeder.feed expects a contiguous (k <= {}, {}) chunk".format(
+                self.chunk, 'x'.join(str(d) for d in self._ring[0].shape[1:])))
         slot = self._next
-        self._next = (self._next + 1) % len(self._ring)
-        if any(s == slot for s, _ in self._queue):
+        if self._left[slot] != 0:
             raise RuntimeError("HostBatchFeeder: ring too small for the batches in flight")
-        dst = self._ring[slot]
+        self._next = (self._next + 1) % len(self._ring)
+        k = host_chunk.shape[0]
+        dst = self._ring[slot][:k]
         if self._free_after[slot] is not None:
             self._copy.wait_event(self._free_after[slot])
         with torch.cuda.stream(self._copy):
-            dst.copy_(host, non_blocking=True)
+            dst.copy_(host_chunk, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self._copy)
-        self.bytes_copied += host.numel() * host.element_size()
-        self._queue.append((slot, dst))
-        self._runner._ready[id(dst)] = ready        # picked up by whichever prefetch() takes the batch
+        self.bytes_copied += host_chunk.numel() * host_chunk.element_size()
+        self._left[slot] = k
+        for j in range(k):
+            view = dst[j]
+            self._queue.append((slot, view))
+            self._runner._ready[id(view)] = ready   # picked up by whichever prefetch() (or step()) takes the batch
 
-    def fill(self, host_batches: Iterable[torch.Tensor]) -> None:
-        """Upload and start sampling for as many of `host_batches` as the pipeline holds (call once before the loop)."""
-        for h in host_batches:
+    def fill(self) -> None:
+        """Start sampling for as many queued batches as the pipeline holds (call after the first feed()s)."""
+        for _, view in list(self._queue)[self._offered:]:
             if self._runner.in_flight() >= self._runner.depth * self._runner.group:
                 break
-            self._upload(h)
-            self._runner.prefetch(self._queue[-1][1], flush=False)
+            self._runner.prefetch(view, flush=False)
             self._offered += 1
 
-    def step(self, next_host: Optional[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Results of the oldest uploaded batch; `next_host` (pinned host tensor, or None at the end of a stream) is
-        uploaded first so that its copy runs beside this batch's kernels."""
-        if next_host is not None and len(self._queue) < len(self._ring) - 1:
-            self._upload(next_host)
+    def pending(self) -> int:
+        return len(self._queue)
+
+    def step(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Results of the oldest queued batch; queued batches the pipeline has room for start sampling first."""
         slot, cur = self._queue[0]
         before, cur_offered = self._runner.prefetched, self._offered > 0
         upcoming = [t for _, t in list(self._queue)[max(1, self._offered):]]
@@ -321,7 +343,9 @@ class HostBatchFeeder:
         self._queue.popleft()
         if cur_offered:
             self._offered -= 1
-        ev = torch.cuda.Event()
-        ev.record()                                  # caller's stream: it has waited for the launch that read `cur`
-        self._free_after[slot] = ev
+        self._left[slot] -= 1
+        if self._left[slot] == 0:
+            ev = torch.cuda.Event()
+            ev.record()                              # caller's stream: it has waited for the launches that read the chunk
+            self._free_after[slot] = ev
         return y

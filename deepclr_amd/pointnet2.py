@@ -81,6 +81,7 @@ class PointnetSAModuleMSG(nn.Module):
             self.mlps.append(_SharedMLP(spec))
         self.fused = fused                       # one-kernel path (csrc/sa.hip); otherwise level-1 operators + dclr_linear
         self._cache = PackedCache()
+        self._range_ok = None                    # weights key of the last checked split-f16 pass (ops.CHECK_RANGE)
 
     def out_features(self) -> int:
         return sum(self._out)
@@ -119,7 +120,21 @@ class PointnetSAModuleMSG(nn.Module):
             sample = self.sample(clouds)
         idx, gpts, gbox = sample
         groups = None if gpts is None else (gpts, gbox)
-        return ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, self.packed_mlps(), groups=groups)
+        mlps = self.packed_mlps()
+        rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups)
+        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':
+            # split-f16 operands clamp at +-65504: the first call after the weights changed (or every call with
+            # CHECK_RANGE = 'always') also runs the f32 matrix instructions and compares (two host syncs, once)
+            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            if ops.CHECK_RANGE == 'always' or key != self._range_ok:
+                want = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, precision='f32')
+                err, scale = float((rows - want).abs().max()), float(want.abs().max())
+                if not err <= 1e-4 * max(1.0, scale) or not scale < ops.F16_MAX:
+                    raise RuntimeError("split-f16 matrix path out of range in set abstraction: features reach {:.4g} "
+                                       "(limit 65504) and differ from the f32 matrix path by {:.3g}; run this checkpoint "
+                                       "with DCLR_PRECISION=f32".format(scale, err))
+                self._range_ok = key
+        return rows
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
                 new_xyz: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

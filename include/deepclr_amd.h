@@ -225,6 +225,13 @@ int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, co
                                   const int32_t *knn_idx, const float *pt, const float *ps, const float *w1a,
                                   const float *b1, const void *w2p, const float *b2, const void *w3p,
                                   const float *b3, float *e_rows, dclr_stream_t stream);
+/* dclr_sa_msg_fused with layers 2 and 3 of the shared MLP (16 -> 16 -> 32) on split-f16 operands; same arguments, same
+ * weight buffers (f32: the kernel splits its fragments itself), same neighbour sets and counts; features agree with the
+ * f32 form to f32 rounding. Activations must stay below 65504. */
+int dclr_sa_msg_fused_f16(int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx,
+                          int n_scales, const float *radii_host, const int *nsamples_host,
+                          const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
+                          const float *group_pts, const float *group_box, dclr_stream_t stream);
 
 /* ---- the dense stages of one batch in one call ----------------------------------------------------------
  * Rows F of [templates..., sources...] -> pose outputs y (pairs, n_out): the launches DeepCLR.forward makes

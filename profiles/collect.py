@@ -36,6 +36,20 @@ KERNEL_TO_SPAN = [('fps_', 'fps_clouds'), ('sa_msg_kernel', 'sa_msg_fused'), ('k
 BENCH_ARGS = {'c2': ['--steps', '60', '--warmup', '20'], 'c4': ['--steps', '6', '--warmup', '2'],
               'c5': ['--steps', '80', '--warmup', '40']}
 CALIB = os.path.join(ROOT, 'profiles', 'calib_copy.py')
+# the measurement lines beside the c2 headline: bench arguments per mode
+MODES = {
+    'driver': ['--steps', '20', '--warmup', '5'],                           # the driver's own arguments
+    'default': [],                                                          # 200 steps
+    'strict': ['--strict', '--steps', '200', '--warmup', '20'],            # one batch of 8 pairs per launch, no cross-batch fusion
+    'serial': ['--no-overlap', '--steps', '100', '--warmup', '10'],        # one batch at a time, one stream
+    'h2d': ['--h2d'],                                                       # batch copied from pinned host memory every step
+    'h2d_driver': ['--h2d', '--steps', '20', '--warmup', '5'],
+    'ring': ['--clouds', 'ring'],                                           # LiDAR-density clouds: nsample caps reached
+    'ring_strict': ['--clouds', 'ring', '--strict', '--steps', '200', '--warmup', '20'],
+    'ring_c5': ['--config', 'c5', '--clouds', 'ring'],
+    'latency': ['--latency', '--steps', '50', '--warmup', '10'],            # B = 1, one pair per predict call
+    'latency_ring': ['--latency', '--clouds', 'ring', '--steps', '50', '--warmup', '10'],
+}
 
 
 def span_of(kernel_name: str, calib: bool = False):
@@ -89,6 +103,8 @@ def main():
     ap.add_argument('--skip-pmc', action='store_true')
     ap.add_argument('--skip-stats', action='store_true')
     ap.add_argument('--install', action='store_true', help='copy the summaries from gpurun_out/<tag>/ into profiles/')
+    ap.add_argument('--modes', default='', help='comma list of the lines beside the headline (MODES below): per mode the '
+                                                'bench line (JSON) and the rocprofv3 kernel-stats summary of the same command')
     args = ap.parse_args()
     out = os.path.join(ROOT, 'gpurun_out', args.tag)
     if args.install:
@@ -100,10 +116,31 @@ def main():
             shutil.copy(traffic, os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))
         return
     os.makedirs(out, exist_ok=True)
+    py = sys.executable
+    for mode in [m for m in args.modes.split(',') if m]:
+        extra = MODES[mode]
+        line = os.path.join(out, '{}_bench_{}.json'.format(args.tag, mode))
+        run([py, 'bench.py'] + extra, line)
+        with open(line) as fh:                                 # keep the JSON line only (stderr chatter goes to the log)
+            txt = fh.read()
+        rows = [l for l in txt.splitlines() if l.startswith('{')]
+        with open(line, 'w') as fh:
+            fh.write((rows[-1] if rows else txt) + '\n')
+        if rows:
+            doc_ = json.loads(rows[-1])
+            print(mode, 'value', round(doc_['value'], 1), doc_['unit'], 'ms/step', round(doc_['ms_per_step'], 4),
+                  'pose', doc_.get('pose_delta_vs_oracle'), flush=True)
+        d = os.path.join(out, 'raw_stats_' + mode)
+        run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', py, 'bench.py'] + extra +
+            ['--no-cpu-baseline', '--no-launch-timer'], os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, mode)))
+        for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+            shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, mode)))
+        shutil.rmtree(d, ignore_errors=True)
+    if args.modes and args.configs == 'none':
+        return
     from bench import kernel_source_hash
     doc = {'_how': __doc__.split('\n\n')[1].replace('\n', ' '), 'commit': git_commit(),
            'kernel_source_hash': kernel_source_hash(), 'configs': {}}
-    py = sys.executable
     fetch_factor = None
     if not args.skip_pmc:
         calib = {}

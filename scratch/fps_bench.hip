@@ -7,12 +7,19 @@
 #include "../deepclr_amd/csrc/fps.hip"
 
 int main(int argc, char **argv) {
-    const int b = 16, n = argc > 1 ? atoi(argv[1]) : 16384, m = argc > 2 ? atoi(argv[2]) : 1024, c = 4;
+    // usage: fps_bench [n] [m] [clouds.bin b]   (clouds.bin: raw f32 (b, n, 4), scratch/make_clouds.py)
+    const char *file = argc > 4 ? argv[3] : nullptr;
+    const int b = file ? atoi(argv[4]) : 16, n = argc > 1 ? atoi(argv[1]) : 16384, m = argc > 2 ? atoi(argv[2]) : 1024, c = 4;
     std::mt19937 rng(1);
     std::normal_distribution<float> g(0.f, 1.f);
     std::vector<float> h((size_t)b * n * c);
     for (size_t i = 0; i < (size_t)b * n; ++i) {
         h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
+    }
+    if (file) {
+        FILE *f = fopen(file, "rb");
+        if (!f || fread(h.data(), 4, h.size(), f) != h.size()) { printf("cannot read %s\n", file); return 1; }
+        fclose(f);
     }
     float *d; int32_t *idx;
     hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4);

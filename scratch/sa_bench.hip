@@ -7,9 +7,12 @@
 #include "../deepclr_amd/csrc/sa.hip"
 
 int main(int argc, char **argv) {
+    // usage: sa_bench [groups 0|1] [modelnet 0|1] [clouds.bin b n]   (clouds.bin: raw f32 (b, n, 4), scratch/make_clouds.py)
     const bool use_groups = argc < 2 || atoi(argv[1]) != 0;
     const bool modelnet = argc > 2 && atoi(argv[2]) != 0;          // 128 clouds of 2048 points on a sphere shell, c = 3
-    const int b = modelnet ? 128 : 16, n = modelnet ? 2048 : 16384, m = modelnet ? 512 : 1024, c = modelnet ? 3 : 4;
+    const char *file = argc > 5 ? argv[3] : nullptr;
+    const int b = file ? atoi(argv[4]) : modelnet ? 128 : 16, n = file ? atoi(argv[5]) : modelnet ? 2048 : 16384,
+              m = modelnet ? 512 : 1024, c = modelnet ? 3 : 4;
     std::mt19937 rng(1);
     std::normal_distribution<float> g(0.f, 1.f);
     std::uniform_real_distribution<float> u(-0.3f, 0.3f);
@@ -23,14 +26,28 @@ int main(int argc, char **argv) {
             h[i * c + 0] = 20.f * g(rng); h[i * c + 1] = 20.f * g(rng); h[i * c + 2] = -1.f + 0.5f * g(rng); h[i * c + 3] = 0.5f;
         }
     }
+    if (file) {
+        FILE *f = fopen(file, "rb");
+        if (!f || fread(h.data(), 4, h.size(), f) != h.size()) { printf("cannot read %s\n", file); return 1; }
+        fclose(f);
+    }
     std::vector<float> w(2 * 896);
     for (auto &v : w) v = u(rng);
     float *d, *gp, *gb, *rows, *wd; int32_t *idx;
-    hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4); hipMalloc(&gp, (size_t)b * 16384 * 16);
-    hipMalloc(&gb, (size_t)b * 64 * 32); hipMalloc(&rows, (size_t)b * m * 68 * 4); hipMalloc(&wd, w.size() * 4);
+    int ng = 64, gs = 256;
+    dclr_fps_group_layout(n, &ng, &gs);
+    hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4); hipMalloc(&gp, (size_t)b * ng * gs * 16);
+    hipMalloc(&gb, (size_t)b * ng * 32); hipMalloc(&rows, (size_t)b * m * 68 * 4); hipMalloc(&wd, w.size() * 4);
     hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(wd, w.data(), w.size() * 4, hipMemcpyHostToDevice);
-    int rc = dclr_fps_clouds_grouped(b, n, c, m, d, idx, gp, gb, nullptr);
+    int rc;
+    if (n > 16384) {
+        void *ws; const long long need = dclr_fps_workspace_bytes(b, n);
+        hipMalloc(&ws, need);
+        rc = dclr_fps_clouds_grouped_ws(b, n, c, m, d, idx, gp, gb, ws, need, nullptr);
+    } else {
+        rc = dclr_fps_clouds_grouped(b, n, c, m, d, idx, gp, gb, nullptr);
+    }
     hipDeviceSynchronize();
     const float radii[2] = {modelnet ? 0.1f : 0.5f, modelnet ? 0.2f : 1.0f}; const int ns[2] = {modelnet ? 256 : 512, modelnet ? 512 : 1024};
     const float *mlps[2] = {wd, wd + 896};
@@ -39,7 +56,8 @@ int main(int argc, char **argv) {
         unsigned long long zero[8] = {0};
         { static std::vector<unsigned long long> z(16384 * 8, 0); hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg_w), z.data(), z.size() * 8); }
         hipEventRecord(e0);
-        int rc2 = dclr_sa_msg_fused(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
+        const bool f16 = getenv("SA_F32") == nullptr;
+        int rc2 = (f16 ? dclr_sa_msg_fused_f16 : dclr_sa_msg_fused)(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
                                     use_groups ? gb : nullptr, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);

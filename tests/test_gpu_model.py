@@ -180,6 +180,10 @@ def _check_set_abstraction(c, n, npoint, radii, nsamples, expect_cap=True):
     fps, gpts, gbox = ops.fps_clouds_grouped(x.to(DEV), npoint)
     assert torch.equal(fps, ops.fps_clouds(x.to(DEV), npoint)) and (gpts is not None) == (n > 1024)
     rows_a, counts = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True)
+    rows_f32, counts_f32 = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True,
+                                            precision='f32')
+    assert torch.equal(counts, counts_f32)
+    _close(rows_a, rows_f32.cpu(), stage='set abstraction: split-f16 vs f32 shared MLP')
     if gpts is not None:                              # spatial-group fast path == exhaustive sweep, bit for bit
         rows_b, counts_b = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(),
                                             want_counts=True, groups=(gpts, gbox))
@@ -597,37 +601,43 @@ def test_pipelined_run_prefetches_every_batch_after_the_first(monkeypatch):
 
 
 def test_host_batch_feeder_matches_resident_batches():
-    """--h2d path of bench.py: batches in pinned host memory, copied on a copy stream into a ring of device buffers that
-    is shorter than the stream of batches (every slot rewritten several times while older batches are still in flight)."""
+    """--h2d path of bench.py: batches in pinned host memory, copied chunk by chunk on a copy stream into a ring of device
+    buffers that is shorter than the stream of batches (every slot rewritten several times while older batches are still in
+    flight); ragged last chunk."""
     from deepclr_amd.pipeline import HostBatchFeeder, PipelinedForward
     cfg = synthetic.model_cfg('kitti')
     model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=23))
-    host = [torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=5 * i)).pin_memory() for i in range(14)]
+    host = [torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=5 * i)) for i in range(14)]
     with torch.no_grad():
         want = [model(h.to(DEV))[0] for h in host]
     torch.cuda.synchronize()
-    for depth, group, dense in ((2, 1, False), (2, 2, True), (1, 3, True)):
+    for depth, group, dense, chunk in ((2, 1, False, 1), (2, 2, True, 2), (1, 3, True, 4), (2, 2, False, 3)):
         runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense, inputs_ready=True)
-        feeder = HostBatchFeeder(runner, host[0].to(DEV))
-        ahead = depth * group
-        feeder.fill(host[:ahead])
-        got = []
-        for i in range(len(host)):
-            nxt = host[i + ahead] if i + ahead < len(host) else None
-            got.append(feeder.step(nxt).clone())
-        assert feeder.bytes_copied == len(host) * host[0].numel() * 4
+        feeder = HostBatchFeeder(runner, host[0].to(DEV), chunk=chunk)
+        chunks = [torch.stack(host[i:i + chunk]).pin_memory() for i in range(0, len(host), chunk)]
+        got, fed = [], 0
+        while len(got) < len(host):
+            while fed < len(chunks) and feeder.room() and feeder.pending() <= depth * group:
+                feeder.feed(chunks[fed])
+                fed += 1
+            got.append(feeder.step().clone())
+        assert feeder.bytes_copied == len(host) * host[0].numel() * 4 and feeder.pending() == 0
         for i, (a, b) in enumerate(zip(got, want)):
-            assert torch.equal(a, b), (depth, group, dense, i)
+            assert torch.equal(a, b), (depth, group, dense, chunk, i)
+    with pytest.raises(RuntimeError):
+        feeder.feed(torch.zeros(1, 4, 100, 4).pin_memory())            # wrong batch shape
 
 
-def test_ring_scan_clouds_reach_the_ball_query_caps_and_match_the_oracle():
+@pytest.mark.parametrize('n, expect_capped', [(16384, False), (65536, True)])
+def test_ring_scan_clouds_crowded_neighbourhoods_match_the_oracle(n, expect_capped):
     """LiDAR-density clouds (deepclr_amd/synthetic.py:ring_scan, bench.py --clouds ring): near the sensor a 1 m ball holds
-    more than nsample = 1024 points, so set abstraction takes its overflow path (roll back, exhaustive in-order sweep).
-    Counts exact, features and poses against the oracle."""
+    hundreds of points at 16384 points per scan (more than the 512-entry staging ring: the centroid is redone with
+    mid-centroid drains) and more than nsample = 1024 at 65536 (the radix select on the point index decides which
+    neighbours count). Sampling and counts exact, features and poses against the oracle."""
     cfg = synthetic.model_cfg('kitti')
     sd = synthetic.random_state_dict(cfg, seed=4)
     model, orc = _models(cfg, sd)
-    x_np = synthetic.make_batch('ring', 1, 16384, first_pair=2)
+    x_np = synthetic.make_batch('ring', 1, n, first_pair=2)
     x = torch.from_numpy(x_np).to(DEV)
     sa = model._cloud_layers[0]._sa0
     fps, gpts, gbox = ops.fps_clouds_grouped(x, 1024)
@@ -635,16 +645,23 @@ def test_ring_scan_clouds_reach_the_ball_query_caps_and_match_the_oracle():
     fps_o = oracle.furthest_point_sample(xyz, 1024)
     assert torch.equal(fps.cpu(), fps_o)
     rows, counts = ops.sa_msg_fused(x, fps, sa.radii, sa.nsamples, sa.packed_mlps(), want_counts=True, groups=(gpts, gbox))
+    rows32, counts32 = ops.sa_msg_fused(x, fps, sa.radii, sa.nsamples, sa.packed_mlps(), want_counts=True,
+                                        groups=(gpts, gbox), precision='f32')
+    assert torch.equal(counts, counts32)
+    _close(rows, rows32.cpu(), stage='ring clouds: split-f16 vs f32 set-abstraction MLP')
+    rows_sweep, counts_sweep = ops.sa_msg_fused(x, fps, sa.radii, sa.nsamples, sa.packed_mlps(), want_counts=True)
+    assert torch.equal(counts, counts_sweep) and torch.equal(rows, rows_sweep)      # groups + radix select == in-order sweep
     new_xyz = torch.gather(xyz, 1, fps_o.long()[:, :, None].expand(-1, -1, 3))
-    capped = 0
+    capped, crowded = 0, 0
     for s, (r, ns) in enumerate(zip(sa.radii, sa.nsamples)):
         bq = oracle.ball_query(r, ns, xyz, new_xyz)
         hits = 1 + (bq[:, :, 1:] != bq[:, :, :1]).sum(-1)
         assert torch.equal(counts[:, :, s].cpu(), hits.to(torch.int32))
         capped += int((hits == ns).sum())
-    assert capped > 0                                               # the caps ARE reached (Gaussian bench clouds: never)
-    print('ring clouds: %d of %d (centroid, scale) neighbourhoods at their nsample cap; mean hits %.1f / %.1f'
-          % (capped, 2 * 2 * 1024, float(counts[:, :, 0].float().mean()), float(counts[:, :, 1].float().mean())))
+        crowded += int((hits > 450).sum())
+    print('ring clouds n=%d: %d (centroid, scale) neighbourhoods at their nsample cap, %d above the staging ring; mean hits '
+          '%.1f / %.1f' % (n, capped, crowded, float(counts[:, :, 0].float().mean()), float(counts[:, :, 1].float().mean())))
+    assert crowded > 0 and (capped > 0 or not expect_capped)
     with torch.no_grad():
         feat = model.cloud_features(x.clone())
         y, _, _ = model(x.clone())
