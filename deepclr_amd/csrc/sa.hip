@@ -157,12 +157,13 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
 #ifdef SA_DEBUG
     SA_STAMP(g2);
 #endif
-#pragma unroll 1
-    for (int t = 0; 16 * t < take; ++t) {
+    // raw third-layer outputs (before bias and ReLU) of the 16 entries of tile t
+    auto tile_mlp = [&](int t, dclr_f32x4 (&h3)[2]) {
         const float x = stg[4 * (16 * t + e16) + kq];                        // input component kq of entry 16 t + e16
         dclr_f32x4 h1 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
         h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, x, h1, 0, 0, 0);
-        dclr_f32x4 h3[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        h3[0] = dclr_f32x4{0.f, 0.f, 0.f, 0.f};
+        h3[1] = dclr_f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (F16) {
             // relu(h1 + b1) as hi / lo halves = the B operand of layer 2 (k = 4 kq + i)
             dclr_h2 p0, q0, p1, q1;
@@ -199,30 +200,60 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
                 h3[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[1][j], h2[j], h3[1], 0, 0, 0);
             }
         }
-        const int cen = tag[16 * t + e16];
-        const int cen0 = __builtin_amdgcn_readfirstlane(cen);
-        if (__ballot(cen != cen0) == 0) {
-            // The 16 entries of the tile (= one DPP row per lane quarter) belong to one centroid -- the common case, the
-            // ring is filled centroid by centroid: reduce over the row first and let one lane per quarter fold the
-            // result. Sixteen lanes hitting the same LDS word serialise: with dense neighbourhoods (ModelNet: ~45
-            // neighbours per centroid) the per-lane atomics were 3/4 of a drain (9.1 k of 12.5 k cycles).
-            if (cen0 >= 0) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const uint32_t v = dclr_row16_max_lanes(__float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
-                        if (e16 == 15) atomicMax(acc + cen0 * SA_OUT + 16 * u + 4 * kq + i, v);
-                    }
-            }
-        } else if (cen >= 0) {
+    };
+    // Fold: max over entries of relu(h + b3) = relu(max over entries of h + b3) (monotone), so consecutive tiles of ONE
+    // centroid -- the rule with dense neighbourhoods, the ring is filled centroid by centroid -- only update a running
+    // per-lane maximum (8 v_max). The reduction over the 16 lanes of a DPP row and the LDS atomic max (one lane per
+    // quarter: sixteen lanes on one LDS word serialise) are paid once per run of tiles instead of once per tile (they
+    // were 32 DPP steps + 8 atomics of ~110 instructions per tile). A tile that mixes centroids (or holds padding
+    // lanes, tag -1) ends the run and folds per lane.
+    int run_cen = -1;                                                        // wave-uniform
+    dclr_f32x4 rmax[2];
+    auto flush = [&]() {
+        if (run_cen >= 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    atomicMax(acc + cen * SA_OUT + 16 * u + 4 * kq + i, __float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t v = dclr_row16_max_lanes(__float_as_uint(fmaxf(rmax[u][i] + c3[u][i], 0.f)));
+                    if (e16 == 15) atomicMax(acc + run_cen * SA_OUT + 16 * u + 4 * kq + i, v);
+                }
         }
+        run_cen = -1;
+    };
+    auto fold = [&](int t, const dclr_f32x4 (&h3)[2]) {
+        const int cen = tag[16 * t + e16];
+        const int cen0 = __builtin_amdgcn_readfirstlane(cen);
+        if (__ballot(cen != cen0) == 0 && cen0 >= 0) {
+            if (cen0 != run_cen) {
+                flush();
+                run_cen = cen0;
+                rmax[0] = h3[0]; rmax[1] = h3[1];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rmax[u][i] = fmaxf(rmax[u][i], h3[u][i]);
+            }
+        } else {
+            flush();
+            if (cen >= 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        atomicMax(acc + cen * SA_OUT + 16 * u + 4 * kq + i, __float_as_uint(fmaxf(h3[u][i] + c3[u][i], 0.f)));
+            }
+        }
+    };
+    const int n_tiles = (take + 15) >> 4;
+#pragma unroll 1
+    for (int t = 0; t < n_tiles; ++t) {
+        dclr_f32x4 ha[2];
+        tile_mlp(t, ha);
+        fold(t, ha);
     }
+    flush();
 #ifdef SA_DEBUG
     SA_STAMP(g3);
     if (lane == 0) { sa_dbg_l[wave][0] += g1 - g0; sa_dbg_l[wave][1] += g3 - g2; }
@@ -242,7 +273,7 @@ __device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz
 
 
 template <int C, int NCH, bool F16>
-__global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
+__global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                                                                const float *__restrict__ clouds,
                                                                const int32_t *__restrict__ fps_idx,
                                                                float *__restrict__ out_rows,
@@ -316,23 +347,32 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
         const float4 *gp = prm.group_pts + bi * (size_t)prm.n_groups * prm.group_size;
         // lane g owns the boxes of groups g, 64 + g, ... (NCH chunks of 64 groups: 1 for the register sampler's <= 64
         // groups, 2 / 4 for the workspace sampler's 128 / 256)
-        float blx[NCH], bly[NCH], blz[NCH], bhx[NCH], bhy[NCH], bhz[NCH];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
+        // (with one chunk the boxes stay in registers for the wave's four centroids; with 2 / 4 chunks they are re-read per
+        // centroid -- 6 L2-resident loads per chunk -- rather than held across the drain calls: 128 registers per wave)
+        auto load_box = [&](int ch, float (&bx)[6]) {
             const bool have = ch * 64 + lane < prm.n_groups;
             const float *gb = prm.group_box + (bi * prm.n_groups + (have ? ch * 64 + lane : 0)) * 8;
-            blx[ch] = have ? gb[0] : 3.0e38f; bly[ch] = have ? gb[1] : 3.0e38f; blz[ch] = have ? gb[2] : 3.0e38f;
-            bhx[ch] = have ? gb[3] : -3.0e38f; bhy[ch] = have ? gb[4] : -3.0e38f; bhz[ch] = have ? gb[5] : -3.0e38f;
-        }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { bx[a] = have ? gb[a] : 3.0e38f; bx[3 + a] = have ? gb[3 + a] : -3.0e38f; }
+        };
+        float box0[6];
+        if constexpr (NCH == 1) load_box(0, box0);
         const int slices = prm.group_size / 64;
 #pragma unroll 1
         for (int c = 0; c < n_live; ++c) {
             const float cx = sa_cxyz[wave][c][0], cy = sa_cxyz[wave][c][1], cz = sa_cxyz[wave][c][2];
             uint64_t gm[NCH];          // groups the largest ball can reach, per chunk (an absent group's bound is +inf)
+            if constexpr (NCH == 1) {
+                gm[0] = __ballot(sa_box_lower_bound(box0[0], box0[1], box0[2], box0[3], box0[4], box0[5], cx, cy, cz) <
+                                 prm.radius2_max);
+            } else {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch)
-                gm[ch] = __ballot(sa_box_lower_bound(blx[ch], bly[ch], blz[ch], bhx[ch], bhy[ch], bhz[ch], cx, cy, cz) <
-                                  prm.radius2_max);
+                for (int ch = 0; ch < NCH; ++ch) {
+                    float bx[6];
+                    load_box(ch, bx);
+                    gm[ch] = __ballot(sa_box_lower_bound(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], cx, cy, cz) < prm.radius2_max);
+                }
+            }
             // One pass: neighbours are staged for the MLP as they are found (any order) and counted. If a cap
             // turns out to be exceeded -- index order then decides which nsample neighbours count -- or the
             // ring would overflow, the centroid's entries are taken back (nothing of it has been drained:
@@ -408,18 +448,28 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                 // Rare (LiDAR near field), wave-local and exact; the exhaustive in-order sweep below is left to calls
                 // without groups. Before: one such centroid sent its whole workgroup through all N points.
                 qn[0] = q0[0]; qn[1] = q0[1];
+                uint64_t ghit[NCH];                                    // groups in which a scan found a hit
                 auto scan = [&](auto &&per_slice) {
 #pragma unroll 1
                     for (int chn = 0; chn < NCH; ++chn) {
+                        ghit[chn] = 0;
 #pragma unroll 1
                         for (uint64_t mm = gm[chn]; mm != 0; mm &= mm - 1) {
                             const float4 *pg = gp + (size_t)(chn * 64 + __builtin_ctzll(mm)) * prm.group_size + lane;
+                            constexpr int SB = NCH >= 4 ? 2 : 4;       // slices per round trip (register budget: 128 per wave)
 #pragma unroll 1
-                            for (int it = 0; it < slices; ++it) {
-                                const float4 qq = pg[it * 64];
-                                const float d2 = dclr_sqdist(cx, cy, cz, qq.x, qq.y, qq.z);
-                                if (__ballot(d2 < prm.radius2_max) == 0) continue;
-                                per_slice(d2, __float_as_uint(qq.w) & 0xFFFFu);
+                            for (int it0 = 0; it0 < slices; it0 += SB) {
+                                float4 qq[SB];
+#pragma unroll
+                                for (int it = 0; it < SB; ++it) qq[it] = pg[(it0 + it < slices ? it0 + it : slices - 1) * 64];
+#pragma unroll
+                                for (int it = 0; it < SB; ++it) {
+                                    if (it0 + it >= slices) break;     // wave-uniform
+                                    const float d2 = dclr_sqdist(cx, cy, cz, qq[it].x, qq[it].y, qq[it].z);
+                                    if (__ballot(d2 < prm.radius2_max) == 0) continue;
+                                    ghit[chn] |= mm & (0 - mm);                // lowest set bit = this group
+                                    per_slice(d2, __float_as_uint(qq[it].w) & 0xFFFFu);
+                                }
                             }
                         }
                     }
@@ -430,6 +480,9 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_msg_kernel(SaParams prm,
                         n1[0] += __builtin_popcountll(__ballot(d2 < prm.radius2[0]));
                         if (prm.n_scales > 1) n1[1] += __builtin_popcountll(__ballot(d2 < prm.radius2[1]));
                     });
+                    // the later passes visit only the groups that hold a hit (a box can reach into the ball without one)
+#pragma unroll
+                    for (int chn = 0; chn < NCH; ++chn) gm[chn] = ghit[chn];
                 }
                 uint32_t thr[SA_MAX_SCALES] = {0xFFFFu, 0xFFFFu};
                 uint32_t *hist = reinterpret_cast<uint32_t *>(sa_obuf[wave]);          // 256 bins (320 words available)
@@ -653,14 +706,14 @@ static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clo
     }
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);
-    const int nch = prm.n_groups <= 64 ? 1 : prm.n_groups <= 128 ? 2 : 4;      // chunks of 64 group boxes per lane
+    const int nch = prm.n_groups <= 64 ? 1 : 4;      // chunks of 64 group boxes per lane (128 groups: two of the four stay empty)
 #define SA_LAUNCH(C_, NCH_, F_)                                                                                          \
     hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_, F_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,    \
                        fps_idx, out_rows, counts)
 #define SA_LAUNCH_C(C_)                                                                                                  \
     do {                                                                                                                 \
-        if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true); else if (nch == 2) SA_LAUNCH(C_, 2, true); else SA_LAUNCH(C_, 4, true); }    \
-        else     { if (nch == 1) SA_LAUNCH(C_, 1, false); else if (nch == 2) SA_LAUNCH(C_, 2, false); else SA_LAUNCH(C_, 4, false); } \
+        if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true); else SA_LAUNCH(C_, 4, true); }                                  \
+        else     { if (nch == 1) SA_LAUNCH(C_, 1, false); else SA_LAUNCH(C_, 4, false); }                                \
     } while (0)
     if (c == 4) SA_LAUNCH_C(4); else SA_LAUNCH_C(3);
 #undef SA_LAUNCH_C

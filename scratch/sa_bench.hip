@@ -1,6 +1,7 @@
 // Diagnostic harness for the set-abstraction kernel (not part of the product): hipcc -DSA_DEBUG ...
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <random>
 #include <vector>
 #include "../deepclr_amd/csrc/fps.hip"
@@ -63,7 +64,12 @@ int main(int argc, char **argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long dbg[8];
         { static std::vector<unsigned long long> w(16384 * 8); hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(sa_dbg_w), w.size() * 8);
-          for (int j = 0; j < 8; ++j) { dbg[j] = 0; for (int i = 0; i < 16384; ++i) dbg[j] += w[(size_t)i * 8 + j]; } }
+          for (int j = 0; j < 8; ++j) { dbg[j] = 0; for (int i = 0; i < 16384; ++i) dbg[j] += w[(size_t)i * 8 + j]; }
+          std::vector<unsigned long long> tot;
+          for (int i = 0; i < 16384; ++i) if (w[(size_t)i * 8 + 5]) tot.push_back(w[(size_t)i * 8]);
+          std::sort(tot.begin(), tot.end());
+          if (!tot.empty()) printf("   per-wave total cycles: median %llu  p90 %llu  p99 %llu  max %llu\n", tot[tot.size() / 2],
+                                   tot[tot.size() * 9 / 10], tot[tot.size() * 99 / 100], tot.back()); }
         const double nw = dbg[5] ? (double)dbg[5] : 1;
         printf("rc=%d/%d groups=%d  %.1f us | per wave (cycles): total %.0f  fast-path(incl drains) %.0f  drains %.0f (%.2f drains)  sweep %.0f | waves %.0f | inside drains: load %.0f mlp+fold %.0f\n",
                rc, rc2, (int)use_groups, ms * 1e3, dbg[0] / nw, dbg[1] / nw, dbg[2] / nw, dbg[3] / nw, dbg[4] / nw, nw, dbg[6] / nw, dbg[7] / nw);
