@@ -304,7 +304,9 @@ __device__ __forceinline__ float fps_box_lower_bound(float lx, float ly, float l
 }
 
 #ifdef FPS_DEBUG
-__device__ unsigned long long fps_dbg[16];     // [0] active (wave, round) count, [1..] cycle sums (wave 0)
+__device__ unsigned long long fps_dbg[16];
+__device__ unsigned int fps_grp[64];
+__device__ unsigned long long fps_bucket[16][6][3];   // per wave, per marks-in-round bucket (0..4, 5 = rewrites>=1...): rounds, cycles, rewrites         // table mode: rounds in which group q was marked (cloud 0)     // [0] active (wave, round) count, [1..] cycle sums (wave 0)
 #define FPS_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
 #endif
 
@@ -317,8 +319,65 @@ struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
     float x, y, z;
 };
 
+// The 12-bit sorting cell. The counting sort only decides which wave / group owns which point (any order yields the
+// same samples), but the tighter the groups' boxes, the fewer groups a sample touches -- here and in set abstraction,
+// which scans the same groups. The 12 bits are dealt to the axes by extent: each next bit halves the axis whose cells
+// are currently the widest, and the key interleaves the bits in that same order (a k-d-like space-filling order).
+// A LiDAR scan (160 x 160 x 4 m) gets 6 + 6 + 0 bits = 2.5 m cells; the former 4 + 4 + 4 bits with one common cell size
+// gave it 10 m cells, 256 of the 4096 bins in use, and a dense cell spanned several groups with identical boxes.
+struct FpsGrid {
+    float scale[3];       // cells per unit length
+    int bits[3];
+    uint32_t order;       // 2 bits per key bit, most significant key bit first: the axis it comes from
+};
+
+__device__ __forceinline__ FpsGrid fps_make_grid(const float (&ext)[3]) {
+    FpsGrid g;
+    float width[3] = {ext[0], ext[1], ext[2]};
+    g.bits[0] = g.bits[1] = g.bits[2] = 0;
+    g.order = 0u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int a = (width[1] > width[0] ? (width[2] > width[1] ? 2 : 1) : (width[2] > width[0] ? 2 : 0));
+        g.order = (g.order << 2) | (uint32_t)a;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            g.bits[c] += a == c ? 1 : 0;
+            width[c] = a == c ? width[c] * 0.5f : width[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g.scale[c] = ext[c] > 0.f ? ((float)(1 << g.bits[c]) - 0.001f) / ext[c] : 0.f;
+    return g;
+}
+
+__device__ __forceinline__ uint32_t fps_cell(const FpsGrid &g, float dx, float dy, float dz) {
+    const float d[3] = {dx, dy, dz};
+    uint32_t q[3];
+    int left[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int v = (int)(d[c] * g.scale[c]);
+        const int top = (1 << g.bits[c]) - 1;
+        q[c] = (uint32_t)(v < 0 ? 0 : (v > top ? top : v));
+        left[c] = g.bits[c];
+    }
+    uint32_t key = 0u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int a = (int)((g.order >> (2 * (11 - i))) & 3u);
+        // the axis' next most significant unused bit
+        const int sh = (a == 0 ? left[0] : a == 1 ? left[1] : left[2]) - 1;
+        const uint32_t qa = a == 0 ? q[0] : a == 1 ? q[1] : q[2];
+        key = (key << 1) | ((qa >> sh) & 1u);
+        left[0] -= a == 0 ? 1 : 0; left[1] -= a == 1 ? 1 : 0; left[2] -= a == 2 ? 1 : 0;
+    }
+    return key;
+}
+
 // WGS threads, P points per thread (WGS * P = padded cloud size, a power of two), G groups per wave.
-template <int WGS, int P, int G, int MODE>      // MODE 0: one sample per barrier round; 1: several (per-wave candidates)
+template <int WGS, int P, int G, int MODE>      // MODE 0: one sample per barrier round; 1: several (per-wave candidates);
+                                                // 3: several, per-GROUP candidate table behind a leader wave (default)
 __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int m,
                                                          const float *__restrict__ pts,
                                                          float *__restrict__ temp,
@@ -334,6 +393,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     __shared__ uint32_t wru[2][16];                        // MULTI: per-wave runner-up (largest other running minimum)
     __shared__ float plist[FPS_J][4];                      // MULTI: the samples accepted for the next round
     __shared__ int plist_n;
+    __shared__ uint4 gtab[64][2];                          // MODE 3: one entry per group: {value, key, runner-up, index}, {x, y, z, -}
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
     // BINS counters (u32), NP sorted indices / tie keys (u16: n <= 16384 and keys < 0xFFFF), then NP cell ids (u16)
@@ -374,34 +434,25 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     if (t < 3) cell[t] = 0ull;
     if (t < 32) cand[t >> 4][t & 15] = FpsCand{0, 0.f, 0.f, 0.f};
     __syncthreads();
-    float ext = 0.f;
+    float ext[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = red[a][0], h = red[3 + a][0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
         lo[a] = l;
-        ext = fmaxf(ext, h - l);
+        ext[a] = h - l;
     }
-    // ---- 2. counting sort by a 12-bit Morton cell (4 bits per axis, one common cell size). The sort
+    // ---- 2. counting sort by a 12-bit cell (bits dealt to the axes by extent, FpsGrid). The sort
     //         only decides which wave owns which point; any order yields the same samples. -----------
-    const float scale = ext > 0.f ? 15.999f / ext : 0.f;
+    const FpsGrid grid = fps_make_grid(ext);
     uint16_t *cellof = sbuf + NP;                          // scratch list of cell ids, dead before `picked` is used
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
-        uint32_t mc = 0u;
         if (k < n) {
-            uint32_t q[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const int c = (int)((pts[(size_t)k * pstride + a] - lo[a]) * scale);
-                q[a] = (uint32_t)(c < 0 ? 0 : (c > 15 ? 15 : c));
-            }
-#pragma unroll
-            for (int bit = 0; bit < 4; ++bit)
-                mc |= (((q[0] >> bit) & 1u) << (3 * bit)) | (((q[1] >> bit) & 1u) << (3 * bit + 1)) |
-                      (((q[2] >> bit) & 1u) << (3 * bit + 2));
+            const float *pk = pts + (size_t)k * pstride;
+            const uint32_t mc = fps_cell(grid, pk[0] - lo[0], pk[1] - lo[1], pk[2] - lo[2]);
             atomicAdd(&hist[mc], 1u);
             cellof[k] = (uint16_t)mc;
         }
@@ -438,7 +489,68 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     // right point on equal distances; groups and lanes are merged with an explicit key comparison.
     // The sorted keys go back to LDS (same positions, now in slot order): the hot loop never needs
     // them in registers, only the winner's key is fetched once per round.
-    uint16_t *skey = sbuf + wave * 64 * P + lane;          // this thread's key of slot jj: skey[jj * 64]
+    // MODE 3 deals the sorted groups out by how often they will be touched instead. Samples spread evenly in SPACE, so a
+    // group is marked in proportion to the size of its box: the sparse outskirts' groups in (nearly) every round, the
+    // dense core's hardly ever (measured: 20 to 300 of 324 rounds). A round lasts as long as its busiest wave, so the
+    // groups are ranked by box size (half the surface area) and dealt in serpentine order: wave w gets ranks w,
+    // 2 NW - 1 - w, 2 NW + w, ... -- every wave one large, one small and two medium groups, and neighbours in space
+    // (adjacent ranks are mostly adjacent regions) on different waves and SIMDs. Costs one extra pass over the points.
+    constexpr bool DEALT = MODE == 3;
+    int dq[G];                                             // sorted group of this wave's group g (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < G; ++g) dq[g] = wave * G + g;
+    if constexpr (DEALT) {
+        constexpr int NGR = NW * G;
+        static_assert(NGR <= 64, "one group per lane");
+        float *ghot = red[0];                              // 64 floats of the 96 in `red` (free again after step 1)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int q = wave * G + g;                    // provisional: the wave's contiguous share
+            float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const int pos = (q * S + i) * 64 + lane;
+                if (pos < n) {
+                    const float *pk = pts + (size_t)sbuf[pos] * pstride;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { blo[a] = fminf(blo[a], pk[a]); bhi[a] = fmaxf(bhi[a], pk[a]); }
+                }
+            }
+            float d[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] = fps_shfl_max(bhi[a]) - fps_shfl_min(blo[a]);
+            if (lane == 0) ghot[q] = d[0] >= 0.f ? d[0] * d[1] + d[1] * d[2] + d[2] * d[0] : -1.0f;   // empty group: last
+        }
+        __syncthreads();
+        const float h = lane < NGR ? ghot[lane] : -2.0f;
+        int rank = 0;
+#pragma unroll 8
+        for (int p2 = 0; p2 < NGR; ++p2) {
+            const float hp = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(h), p2));
+            rank += (hp > h || (hp == h && p2 < lane)) ? 1 : 0;
+        }
+        const int level = rank / NW, along = rank % NW;
+        const int owner = (level & 1) ? NW - 1 - along : along;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint64_t mine = __ballot(lane < NGR && level == g && owner == wave);
+            dq[g] = mine != 0 ? __builtin_ctzll(mine) : wave * G + g;
+        }
+        __syncthreads();                                   // `red` is read again below only after further barriers; be safe
+    }
+    auto deal = [&](int g) -> int {                        // g is a compile-time constant in every unrolled caller
+        int q = dq[0];
+#pragma unroll
+        for (int u = 1; u < G; ++u) q = g == u ? dq[u] : q;
+        return q;
+    };
+    auto slot_pos = [&](int jj, int ln) -> int {           // position in sbuf of lane ln's slot jj (this wave); jj a constant
+        if constexpr (DEALT) return (deal(jj / S) * S + (jj % S)) * 64 + ln;
+        else return wave * 64 * P + jj * 64 + ln;
+    };
+    auto slot_pos_g = [&](int g, int jj, int ln) -> int {  // the same for a slot of group g (a constant) given at run time
+        return (deal(g) * S + (jj - g * S)) * 64 + ln;
+    };
     vec px, py, pz, td;
     float glo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};   // lane g: box of group g
     float gmaxv = 0.f;                                     // lane g: upper bound of group g's largest running minimum;
@@ -450,7 +562,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         uint32_t tkg[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            const int pos = wave * 64 * P + (g * S + i) * 64 + lane;
+            const int pos = slot_pos(g * S + i, lane);
             tkg[i] = pos < n ? fps_tk1024(sbuf[pos]) : 0xFFFFu;
         }
 #pragma unroll
@@ -473,7 +585,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int jj = g * S + i;
-            skey[jj * 64] = (uint16_t)tkg[i];              // own positions only: no cross-thread hazard
+            sbuf[slot_pos(jj, lane)] = (uint16_t)tkg[i];   // own positions only: no cross-thread hazard
             float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;   // -2: padding can never beat best = -1
             if (tkg[i] != 0xFFFFu) {
                 const uint32_t k = fps_tk1024_inv(tkg[i]);
@@ -525,6 +637,316 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     unsigned long long acc_upd = 0, acc_bar = 0, acc_comb = 0, n_act = 0;
     unsigned long long dbg_box = 0, dbg_upd = 0, dbg_sel = 0, dbg_pub = 0, dbg_idle = 0, dbg_nact = 0;
 #endif
+    if constexpr (MODE == 3) {
+        // ---- several samples per barrier round, one table entry per GROUP, everything global done by a leader wave ----
+        // The CU is issue-bound here (16 waves share 4 SIMDs and every instruction of every wave counts), so a round is
+        // laid out for the fewest instructions in total:
+        //   table    every group (64 S points) keeps an exact entry in LDS: its largest running minimum b_g, that point's
+        //            tie key, index and coordinates, and the runner-up u_g (largest running minimum among the group's
+        //            OTHER points); its bounding box sits beside it;
+        //   leader   (wave 0, lane = group) reads the <= 64 entries. p1 = best entry overall is sample r. The best
+        //            remaining entry c (value v) is sample r + 1 as well if sqdist(c, p1) >= v (p1 leaves it untouched) and
+        //            u_{g(p1)} < v (nothing else in p1's group can reach it; running minima only decrease): every other
+        //            point is already ordered behind c by its group's arg-max (ties by key). The same test against every
+        //            sample accepted so far admits c as sample r + j. The J candidates are extracted first (J chained
+        //            wave maxima), then all tests run side by side. The leader ALSO tests every accepted sample against
+        //            all group boxes at once (one lane per group: a group can change iff the rounded lower bound of its
+        //            distance to the sample is below b_g) and publishes one 64-bit mask per sample;
+        //   workers  a wave looks up its groups' bits: none set (the usual case) -> straight to the next barrier.
+        //            Otherwise each marked group takes exactly the samples that marked it, then one pass finds the lane's
+        //            best and second-best slot, one top-2 reduction over the wave gives b_g and u_g, and lane 0 rewrites
+        //            the entry.
+        // Against per-wave candidates (MODE 1): 3.1 instead of 2.4 samples per round on the bench clouds (the runner-up of
+        // 64 S points instead of 1024 stands in the way less often); no wave but the leader runs box tests (they were
+        // 40 % of the instructions of a round); the groups are dealt out round-robin, so the handful a sample touches
+        // are updated on different SIMDs; and the picks are not one serial chain of test -> pick -> test.
+        constexpr int J = FPS_J > 4 ? FPS_J : 4, NG = NW * G;
+        static_assert(NG <= 64 && J <= 8, "one table entry per lane, one (j, i) pair of candidates per lane");
+        __shared__ float gbox[64][8];                     // box of group q (min xyz, max xyz), written once
+        __shared__ float4 rb_s[8];                        // the round's samples: x, y, z, -
+        __shared__ unsigned long long rb_m[8];            // ... and the groups each of them can change
+        float gval = gmaxv;                               // lane g < G: b_g of this wave's group g
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (lane == g) {
+                const int q = dq[g];
+                // a non-empty group starts at +inf (gmaxv): sample 0 then marks it; an empty one stays at 0 (bound +inf: never marked)
+                gtab[q][0] = make_uint4(__float_as_uint(gval), 0xFFFFu, 0u, 0u);
+                gtab[q][1] = make_uint4(0u, 0u, 0u, 0u);
+                gbox[q][0] = glo[0]; gbox[q][1] = glo[1]; gbox[q][2] = glo[2];
+                gbox[q][3] = ghi[0]; gbox[q][4] = ghi[1]; gbox[q][5] = ghi[2];
+            }
+        }
+        if (t < 8) {
+            // round 1: sample 0 = point 0, marked for every group (the table is not built yet)
+            rb_s[t] = make_float4(cx, cy, cz, 0.f);
+            rb_m[t] = t == 0 ? ~0ull : 0ull;
+        }
+        __syncthreads();
+        // bits of this wave's groups in a mask: group g of this wave is table entry deal(g)
+        unsigned long long own = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) own |= 1ull << deal(g);
+        int sr = 0;
+        int cur_wl[G], cur_jj[G];                         // per group of this wave: lane and slot holding the entry's point ...
+        uint32_t cur_b[G];                                // ... and b_g as last published (wave-uniform; ~0: none yet)
+#pragma unroll
+        for (int g = 0; g < G; ++g) { cur_wl[g] = 0; cur_jj[g] = g * S; cur_b[g] = 0xFFFFFFFFu; }
+#ifdef FPS_DEBUG
+        unsigned long long mu = 0, mb = 0, mc = 0, mt = 0, mg = 0, mr = 0, mg_prev = 0, mr_prev = 0;
+#endif
+        for (int r = 0;;) {                                               // r: samples picked so far
+#ifdef FPS_DEBUG
+            unsigned long long q0, q1, q2, q3;
+            FPS_STAMP(q0);
+#endif
+            // -- workers ------------------------------------------------------------------------------------------
+            const unsigned long long mmask = rb_m[lane & 7];              // lane j < J: the groups sample j can change
+            const float4 smp = rb_s[lane & 7];                            // ... and the sample (read now: one LDS round trip, not two)
+            const uint32_t live = (uint32_t)__ballot(lane < J && mmask != 0ull);       // the samples picked last (each marks its own group)
+            r += __builtin_popcount(live);
+            if (r >= m) break;                                            // all picked (the last ones are never applied: see `temp`)
+            const uint32_t mine = (uint32_t)__ballot(lane < J && (mmask & own) != 0ull);
+            if (mine != 0) {                                              // wave-uniform: some sample reaches a group of this wave
+#ifdef FPS_DEBUG
+                mt += 1;
+#endif
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const unsigned long long gbit = 1ull << deal(g);
+                    const uint32_t sel = (uint32_t)__ballot(lane < J && (mmask & gbit) != 0ull);
+                    if (sel == 0) continue;                               // wave-uniform
+#ifdef FPS_DEBUG
+                    mg += 1;
+#endif
+                    // the samples that marked this group, one after the other over the S slots of the lane's cell
+                    // (two slots per instruction: v_pk_add_f32 / v_pk_mul_f32 are the IEEE operations of dclr_sqdist in the
+                    // same order, so the distances are bit-identical)
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    for (uint32_t rem = sel; rem != 0; rem &= rem - 1) {
+                        const int j = __builtin_ctz(rem);
+                        const float sx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(smp.x), j));
+                        const float sy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(smp.y), j));
+                        const float sz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(smp.z), j));
+                        if constexpr (S % 2 == 0) {
+                            const f2 c2x = {sx, sx}, c2y = {sy, sy}, c2z = {sz, sz};
+#pragma unroll
+                            for (int i = 0; i < S; i += 2) {
+                                const int jj = g * S + i;
+                                const f2 ax = {vec_get<P>(px, jj), vec_get<P>(px, jj + 1)};
+                                const f2 ay = {vec_get<P>(py, jj), vec_get<P>(py, jj + 1)};
+                                const f2 az = {vec_get<P>(pz, jj), vec_get<P>(pz, jj + 1)};
+                                const f2 dx = ax - c2x, dy = ay - c2y, dz = az - c2z;
+                                const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                                const f2 d = (xx + yy) + zz;
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    float d2;
+                                    asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d[h]), "v"(vec_get<P>(td, jj + h)));
+                                    vec_set<P>(td, jj + h, d2);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < S; ++i) {
+                                const int jj = g * S + i;
+                                const float d = dclr_sqdist(vec_get<P>(px, jj), vec_get<P>(py, jj), vec_get<P>(pz, jj), sx, sy, sz);
+                                float d2;
+                                asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(vec_get<P>(td, jj)));
+                                vec_set<P>(td, jj, d2);
+                            }
+                        }
+                    }
+                    // Did the group's best point keep its value? Running minima only decrease, so then b_g and the entry's
+                    // point stand; the runner-up in the table may now be too large, which only makes the leader's test
+                    // (v > u_g) more cautious. Most updates nibble at a group's fringe and end here.
+                    // (the entry's own SLOT is checked, not its lane's maximum: on tie-heavy clouds another slot of the lane
+                    // may hold the same value, and then the entry has to move to that point)
+                    {
+                        float ev = vec_get<P>(td, g * S);
+#pragma unroll
+                        for (int i = 1; i < S; ++i) ev = cur_jj[g] == g * S + i ? vec_get<P>(td, g * S + i) : ev;   // uniform selects
+                        const uint32_t now = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ev), cur_wl[g]);
+                        if (now == cur_b[g]) continue;                    // wave-uniform
+                    }
+#ifdef FPS_DEBUG
+                    mr += 1;
+#endif
+                    // this lane's best and second-best slot (slots ascend in tie key: strict > keeps the first)
+                    float best = -1.0f, sec = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+                    int bjj = g * S;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        const int jj = g * S + i;
+                        const float v = vec_get<P>(td, jj);
+                        const bool gt = v > best;
+                        sec = fmaxf(sec, gt ? best : v);
+                        bjj = gt ? jj : bjj;
+                        bx = gt ? vec_get<P>(px, jj) : bx; by = gt ? vec_get<P>(py, jj) : by; bz = gt ? vec_get<P>(pz, jj) : bz;
+                        best = gt ? v : best;
+                    }
+                    // the group: top-2 over the wave of (best, second) per lane (padding and exhausted cells count as 0)
+                    uint32_t m1 = best < 0.f ? 0u : __float_as_uint(best), m2 = sec < 0.f ? 0u : __float_as_uint(sec);
+                    const uint32_t mybest = m1;
+#define FPS_TOP2_STEP(CTRL, RM)                                                                     \
+                    {                                                                               \
+                        const uint32_t o1 = dclr_dpp<CTRL, RM>(0u, m1), o2 = dclr_dpp<CTRL, RM>(0u, m2); \
+                        const uint32_t lo = dclr_umin(m1, o1);                                      \
+                        m1 = dclr_umax(m1, o1);                                                     \
+                        m2 = dclr_umax(dclr_umax(m2, o2), lo);                                      \
+                    }
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(1), 0xf)
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(2), 0xf)
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(4), 0xf)
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(8), 0xf)
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_BCAST15, 0xa)
+                    FPS_TOP2_STEP(DCLR_DPP_ROW_BCAST31, 0xc)
+#undef FPS_TOP2_STEP
+                    const uint32_t gm1 = (uint32_t)__builtin_amdgcn_readlane((int)m1, 63);
+                    const uint32_t gm2 = (uint32_t)__builtin_amdgcn_readlane((int)m2, 63);
+                    const bool real = best >= 0.f;
+                    const uint64_t hit = __ballot(real && mybest == gm1);
+                    int wl, wjj;
+                    uint32_t wkey;
+                    if ((hit & (hit - 1)) == 0) {                         // one lane holds the maximum (the usual case)
+                        wl = hit != 0 ? __builtin_ctzll(hit) : 0;
+                        wjj = __builtin_amdgcn_readlane(bjj, wl);
+                        wkey = sbuf[slot_pos_g(g, wjj, wl)];
+                    } else {                                              // exact tie: smallest tie key among the holders
+                        uint32_t key = 0xFFFFFFFFu;
+                        if (real && mybest == gm1) key = sbuf[slot_pos_g(g, bjj, lane)];
+                        wkey = dclr_wave_min_u32(key);
+                        wl = __builtin_ctzll(__ballot(key == wkey));
+                        wjj = __builtin_amdgcn_readlane(bjj, wl);
+                    }
+                    const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bx), wl));
+                    const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(by), wl));
+                    const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bz), wl));
+                    cur_wl[g] = wl; cur_jj[g] = wjj; cur_b[g] = gm1;
+                    if (lane == 0) {
+                        gtab[deal(g)][0] = make_uint4(gm1, wkey, gm2, fps_tk1024_inv(wkey));
+                        gtab[deal(g)][1] = make_uint4(__float_as_uint(wx), __float_as_uint(wy), __float_as_uint(wz), 0u);
+                    }
+                }
+            }
+#ifdef FPS_DEBUG
+            FPS_STAMP(q1);
+#endif
+            __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(q2);
+#endif
+            // -- leader: the next samples from the table, and the groups each of them can change ----------------------
+            if (wave == 0) {
+                const int le = lane < NG ? lane : 0;
+                const uint4 e0 = gtab[le][0], e1 = gtab[le][1];
+                const float4 blo = *reinterpret_cast<const float4 *>(&gbox[le][0]);      // min x y z, max x
+                const float2 bhi = *reinterpret_cast<const float2 *>(&gbox[le][4]);      // max y z
+                const uint32_t val = lane < NG ? e0.x : 0u;               // b_g (the box test below needs it unmasked)
+                uint32_t v = val;
+                const uint32_t tk = lane < NG ? e0.y : 0xFFFFFFFFu;
+                int wid[J];
+                uint32_t mv[J];
+                bool tie = false;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {                             // J chained wave maxima: candidates in value order
+                    mv[j] = dclr_wave_max_u32(v);
+                    const uint64_t holders = __ballot(v == mv[j]);
+                    tie = tie || (holders & (holders - 1)) != 0;
+                    wid[j] = __builtin_ctzll(holders);
+                    v = lane == wid[j] ? 0u : v;
+                }
+                if (tie) {
+                    // two entries share a value (duplicate points, lattices, an exhausted cloud): again, by (value, key).
+                    // Kept out of the loop above so that the usual round is one straight run of instructions in which the
+                    // box tests and crossbar reads below fill the wait states of the reductions.
+                    v = val;
+#pragma unroll 1
+                    for (int j = 0; j < J; ++j) {
+                        const uint32_t mx = dclr_wave_max_u32(v);
+                        const uint32_t kmin = dclr_wave_min_u32(v == mx ? tk : 0xFFFFFFFFu);
+                        const int w = __builtin_ctzll(__ballot(v == mx && tk == kmin));
+#pragma unroll
+                        for (int u = 0; u < J; ++u) { if (u == j) { wid[u] = w; mv[u] = mx; } }
+                        v = lane == w ? 0u : v;
+                    }
+                }
+                // The tests of candidate j against the earlier ones, one (j, i) pair per lane: lane 4 j + i fetches both
+                // entries through the LDS crossbar (ds_bpermute) and evaluates "v_j > u_i and sqdist(c_j, c_i) >= v_j" --
+                // one distance computation for all pairs instead of one per pair on wave-uniform operands.
+                const int lj = lane >> 3, li = lane & 7;                   // lane 8 j + i: candidate j against candidate i
+                int src_j = wid[0], src_i = wid[0];
+#pragma unroll
+                for (int u = 1; u < J; ++u) { src_j = lj == u ? wid[u] : src_j; src_i = li == u ? wid[u] : src_i; }
+                const float xj = __shfl(__uint_as_float(e1.x), src_j), yj = __shfl(__uint_as_float(e1.y), src_j),
+                            zj = __shfl(__uint_as_float(e1.z), src_j);
+                const float xi = __shfl(__uint_as_float(e1.x), src_i), yi = __shfl(__uint_as_float(e1.y), src_i),
+                            zi = __shfl(__uint_as_float(e1.z), src_i);
+                const uint32_t vj = (uint32_t)__shfl((int)val, src_j), ui = (uint32_t)__shfl((int)e0.z, src_i);
+                const int kj = __shfl((int)e0.w, src_j);
+                const uint32_t dji = __float_as_uint(dclr_sqdist(xj, yj, zj, xi, yi, zi));
+                const bool pair_bad = lj < J && li < lj && !(vj > ui && dji >= vj);
+                const unsigned long long bad = __ballot(pair_bad);         // bits 8 j .. 8 j + 7: candidate j fails a test
+                // candidate j joins iff every earlier one did; the level-1 contract (temp = minima over the first m - 1
+                // samples) gives the final sample a round of its own
+                int cnt = 1;
+                bool open = true;
+#pragma unroll
+                for (int j = 1; j < J; ++j) {
+                    const bool ok = r + j < m && !(temp != nullptr && r + j == m - 1) && mv[j] != 0u && ((bad >> (8 * j)) & 0xFFull) == 0ull;
+                    open = open && ok;
+                    cnt += open ? 1 : 0;
+                }
+                // which groups can candidate j change? lane = group (all J computed, the masks of the rejected ones are dropped)
+                unsigned long long am[J];
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float sx = __uint_as_float(__builtin_amdgcn_readlane((int)e1.x, wid[j]));
+                    const float sy = __uint_as_float(__builtin_amdgcn_readlane((int)e1.y, wid[j]));
+                    const float sz = __uint_as_float(__builtin_amdgcn_readlane((int)e1.z, wid[j]));
+                    const float lbv = fps_box_lower_bound(blo.x, blo.y, blo.z, blo.w, bhi.x, bhi.y, sx, sy, sz);
+                    // (its own group is always marked: with b_g = 0, an exhausted cloud, the box test marks nothing, and the
+                    // workers count the accepted samples by their non-empty masks)
+                    am[j] = j < cnt ? (__ballot(lane < NG && lbv < __uint_as_float(val)) | (1ull << wid[j])) : 0ull;
+                }
+#ifdef FPS_DEBUG
+                if (blockIdx.x == 0) {
+                    unsigned long long all = 0;
+#pragma unroll
+                    for (int u = 0; u < J; ++u) all |= am[u];
+                    if ((all >> lane) & 1ull) fps_grp[lane] += 1;
+                }
+#endif
+                if (lj < J && li == 0) {                                  // lanes 0, 8, 16, ... publish candidates 0, 1, 2, ...
+                    unsigned long long om = am[0];
+#pragma unroll
+                    for (int u = 1; u < J; ++u) om = lj == u ? am[u] : om;
+                    rb_s[lj] = make_float4(xj, yj, zj, 0.f);
+                    rb_m[lj] = om;
+                    if (lj < cnt) picked[r + lj] = kj;
+                }
+            }
+            __syncthreads();
+            sr += 1;
+#ifdef FPS_DEBUG
+            FPS_STAMP(q3);
+            mu += q1 - q0; mb += q2 - q1; mc += q3 - q2;
+            if (lane == 0 && blockIdx.x == 0) {
+                const int nm = (int)(mg - mg_prev) > 4 ? 4 : (int)(mg - mg_prev);
+                fps_bucket[wave][nm][0] += 1; fps_bucket[wave][nm][1] += q1 - q0; fps_bucket[wave][nm][2] += mr - mr_prev;
+            }
+            mg_prev = mg; mr_prev = mr;
+#endif
+        }
+        if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
+#ifdef FPS_DEBUG
+        if (lane == 0 && blockIdx.x == 0) {
+            fps_dbg[11] = (unsigned long long)sr;
+            if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = mg; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; fps_dbg[7] = mr; }
+            if (wave == 0) { fps_dbg[1] = mu; fps_dbg[2] = mb; fps_dbg[3] = mc; fps_dbg[5] = mt; fps_dbg[6] = mg; fps_dbg[8] = mr; }
+        }
+#endif
+    } else
     if constexpr (MODE == 1) {
         // ---- several samples per barrier round -----------------------------------------------------------
         // Sample r+1 is the point with the largest running minimum AFTER sample r has been applied. Let every
@@ -634,14 +1056,14 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
                     wl = __builtin_ctzll(lanes_hit);
                     wjj = __builtin_amdgcn_readlane(hjj, wl);
-                    wkey = sbuf[wave * 64 * P + wjj * 64 + wl];
+                    wkey = sbuf[slot_pos(wjj, wl)];
                 } else {
                     uint32_t key = 0xFFFFFFFFu;
                     int kjj = 0;
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         uint32_t kg = 0xFFFFu;
-                        if (gbest[g] == wmaxf) kg = skey[gjj[g] * 64];
+                        if (gbest[g] == wmaxf) kg = sbuf[slot_pos(gjj[g], lane)];
                         const bool take = gbest[g] == wmaxf && kg < key;
                         key = take ? kg : key;
                         kjj = take ? gjj[g] : kjj;
@@ -841,7 +1263,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
             if (__builtin_popcountll(lanes_hit) == 1 && __ballot(hits > 1) == 0) {
                 wl = __builtin_ctzll(lanes_hit);
                 wjj = __builtin_amdgcn_readlane(hjj, wl);
-                wkey = sbuf[wave * 64 * P + wjj * 64 + wl];                               // uniform address
+                wkey = sbuf[slot_pos(wjj, wl)];                                           // uniform address
             } else {
                 // exact tie (duplicate points, lattices, exhausted cloud): smallest tie key among all
                 // candidates. A group's cached slot already is its lowest-key maximum (ascending keys,
@@ -851,7 +1273,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     uint32_t kg = 0xFFFFu;
-                    if (gbest[g] == wmaxf) kg = skey[gjj[g] * 64];
+                    if (gbest[g] == wmaxf) kg = sbuf[slot_pos(gjj[g], lane)];
                     const bool take = gbest[g] == wmaxf && kg < key;
                     key = take ? kg : key;
                     kjj = take ? gjj[g] : kjj;
@@ -920,7 +1342,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     if (temp) {
 #pragma unroll
         for (int jj = 0; jj < P; ++jj)
-            if (skey[jj * 64] != 0xFFFFu) temp[fps_tk1024_inv(skey[jj * 64])] = vec_get<P>(td, jj);
+            if (sbuf[slot_pos(jj, lane)] != 0xFFFFu) temp[fps_tk1024_inv(sbuf[slot_pos(jj, lane)])] = vec_get<P>(td, jj);
     }
 }
 
@@ -1028,28 +1450,20 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     if (t < 3) cell[t] = 0ull;
     if (t < 32) cand[t >> 4][t & 15] = FpsCand{0, 0.f, 0.f, 0.f};
     __syncthreads();
-    float ext = 0.f;
+    float ext[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = red[a][0], h = red[3 + a][0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
         lo[a] = l;
-        ext = fmaxf(ext, h - l);
+        ext[a] = h - l;
     }
-    // ---- 2. counting sort by 12-bit Morton cell (any order yields the same samples) ---------------
-    const float scale = ext > 0.f ? 15.999f / ext : 0.f;
+    // ---- 2. counting sort by a 12-bit cell, bits dealt to the axes by extent (any order yields the same samples) ----
+    const FpsGrid grid = fps_make_grid(ext);
     for (int k = t; k < n; k += WGS) {
-        uint32_t q[3], mc = 0u;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const int c = (int)((pts[(size_t)k * pstride + a] - lo[a]) * scale);
-            q[a] = (uint32_t)(c < 0 ? 0 : (c > 15 ? 15 : c));
-        }
-#pragma unroll
-        for (int bit = 0; bit < 4; ++bit)
-            mc |= (((q[0] >> bit) & 1u) << (3 * bit)) | (((q[1] >> bit) & 1u) << (3 * bit + 1)) |
-                  (((q[2] >> bit) & 1u) << (3 * bit + 2));
+        const float *pk = pts + (size_t)k * pstride;
+        const uint32_t mc = fps_cell(grid, pk[0] - lo[0], pk[1] - lo[1], pk[2] - lo[2]);
         atomicAdd(&hist[mc], 1u);
         cellof[k] = (uint16_t)mc;
     }
@@ -1435,12 +1849,17 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
     // A/B switches: DCLR_FPS_SINGLE = one sample per barrier round, DCLR_FPS_WAVECAND = several with per-wave candidates
-    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
+    // A/B switches (same samples): DCLR_FPS_SINGLE = one sample per barrier round, DCLR_FPS_WAVECAND = several with per-wave
+    // candidates (round 2's kernel); default = several with the per-group table
+    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_WAVECAND") ? 1 : 3;
     if (mode == 0)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 0>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
+                           group_pts, group_box);
+    else
+        hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 3>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
                            group_pts, group_box);
 }
 

@@ -38,6 +38,26 @@ int main(int argc, char **argv) {
         printf("rc=%d  %.1f us | active groups/round %.2f of 64 | cycles/round wave0/cloud0: update+publish %.0f barrier-wait %.0f combine %.0f total %.0f\n",
                rc, ms * 1e3, dbg[0] / (rounds * b), dbg[1] / rounds, dbg[2] / rounds, dbg[3] / rounds, dbg[4] / rounds);
         printf("   super-rounds: %llu for %d samples | wave 3 per super-round (cycles): updates %.0f select %.0f publish+barrier %.0f combine %.0f | touched in %llu\n", dbg[11], m - 1, (double)dbg[12] / dbg[11], (double)dbg[13] / dbg[11], (double)dbg[14] / dbg[11], (double)dbg[15] / dbg[11], dbg[10]);
+        if (!getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE") && dbg[11])
+            printf("   table mode: %llu rounds (%.2f samples/round) | per round (cycles): wave 3: work %.0f wait-A %.0f leader+B %.0f, touched in %llu rounds, %llu group updates | wave 0: work %.0f wait-A %.0f leader+B %.0f, touched in %llu, %llu group updates\n",
+                   dbg[11], (double)(m - 1) / dbg[11], (double)dbg[12] / dbg[11], (double)dbg[14] / dbg[11], (double)dbg[15] / dbg[11], dbg[10], dbg[13],
+                   (double)dbg[1] / dbg[11], (double)dbg[2] / dbg[11], (double)dbg[3] / dbg[11], dbg[5], dbg[6]);
+        if (!getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE") && dbg[11])
+            printf("   entries rewritten: wave 3 %llu of %llu group updates, wave 0 %llu of %llu\n", dbg[7], dbg[13], dbg[8], dbg[6]);
+        if (rep == 2 && !getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE")) {
+            unsigned int grp[64];
+            hipMemcpyFromSymbol(grp, HIP_SYMBOL(fps_grp), sizeof(grp));
+            unsigned long long bk[16][6][3];
+            hipMemcpyFromSymbol(bk, HIP_SYMBOL(fps_bucket), sizeof(bk));
+            for (int nm = 0; nm <= 4; ++nm) {
+                unsigned long long rounds = 0, cyc = 0, rw = 0;
+                for (int w = 0; w < 16; ++w) { rounds += bk[w][nm][0]; cyc += bk[w][nm][1]; rw += bk[w][nm][2]; }
+                if (rounds) printf("   (wave, round) pairs with %d%s marks: %llu, mean work %.0f cycles, %.2f entry rewrites\n", nm, nm == 4 ? "+" : "", rounds, (double)cyc / rounds, (double)rw / rounds);
+            }
+            printf("   marks per group (3 reps):");
+            for (int q = 0; q < 64; ++q) printf(" %u", grp[q]);
+            printf("\n");
+        }
         for (int w = 0; w < 2; ++w) {
             const unsigned long long *d = dbg + 8 * w;
             if (d[4]) printf("   chains mode, wave %d: rounds %llu picks %llu | per round (cycles): apply %.0f chain %.0f publish+barrier %.0f merge(+barrier) %.0f\n",
