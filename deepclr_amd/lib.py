@@ -23,6 +23,8 @@ SIGNATURES = {
     'dclr_gather_points': [_i, _i, _i, _i, _p, _p, _p, _p],
     'dclr_ball_query': [_i, _i, _i, _f, _i, _p, _p, _p, _p],
     'dclr_group_points': [_i, _i, _i, _i, _i, _p, _p, _p, _p],
+    'dclr_gather_points_grad': [_i, _i, _i, _i, _p, _p, _p, _p],
+    'dclr_group_points_grad': [_i, _i, _i, _i, _i, _p, _p, _p, _p],
     'dclr_knn': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_fps_clouds': [_i, _i, _i, _i, _p, _p, _p],
     'dclr_fps_group_layout': [_i, _p, _p],

@@ -108,6 +108,29 @@ def grouping_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tenso
     return out
 
 
+def gather_operation_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torch.Tensor:
+    """Backward of gather_operation: grad_out (B, C, npoint), idx (B, npoint) int32 -> grad_features (B, C, n)."""
+    grad_out = lib.dev_f32(grad_out, 'grad_out')
+    b, c, npoint = grad_out.shape
+    assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape == (b, npoint)
+    grad = torch.zeros(b, c, n, dtype=torch.float32, device=grad_out.device)
+    _call('dclr_gather_points_grad', 'gather_operation_grad', b, c, n, npoint, grad_out.data_ptr(), idx.data_ptr(),
+          grad.data_ptr(), lib.stream_ptr())
+    return grad
+
+
+def grouping_operation_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -> torch.Tensor:
+    """Backward of grouping_operation: grad_out (B, C, npoint, nsample), idx (B, npoint, nsample) int32 ->
+    grad_features (B, C, n)."""
+    grad_out = lib.dev_f32(grad_out, 'grad_out')
+    b, c, npoint, nsample = grad_out.shape
+    assert idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and idx.shape == (b, npoint, nsample)
+    grad = torch.zeros(b, c, n, dtype=torch.float32, device=grad_out.device)
+    _call('dclr_group_points_grad', 'grouping_operation_grad', b, c, n, npoint, nsample, grad_out.data_ptr(), idx.data_ptr(),
+          grad.data_ptr(), lib.stream_ptr())
+    return grad
+
+
 def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor] = None,
         batch_y: Optional[torch.Tensor] = None, batch_size: Optional[int] = None) -> torch.Tensor:
     """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index].

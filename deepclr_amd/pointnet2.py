@@ -23,11 +23,49 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ball_query, furthest_point_sample, gather_operation, grouping_operation  # noqa: F401
+from .ops import ball_query, furthest_point_sample  # noqa: F401  (index outputs: nothing to differentiate)
 from .models.helper import PackedCache
 
 __all__ = ['PointnetSAModuleMSG', 'furthest_point_sample', 'gather_operation', 'ball_query',
-           'grouping_operation']
+           'grouping_operation', 'GatherOperation', 'GroupingOperation']
+
+
+class GatherOperation(torch.autograd.Function):
+    """features (B, C, N), idx (B, npoint) int32 -> (B, C, npoint); backward scatters the gradient back
+    (upstream pointnet2_utils.GatherOperation over gather_points_wrapper_fast / gather_points_grad_wrapper_fast,
+    /root/reference/extern/pointnet2.patch:275-304)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(idx)
+        ctx.n = features.shape[2]
+        return ops.gather_operation(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        (idx,) = ctx.saved_tensors
+        return ops.gather_operation_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+class GroupingOperation(torch.autograd.Function):
+    """features (B, C, N), idx (B, npoint, nsample) int32 -> (B, C, npoint, nsample); backward sums the gradient of
+    every slot into its source point (upstream pointnet2_utils.GroupingOperation over group_points_wrapper_fast /
+    group_points_grad_wrapper_fast, /root/reference/extern/pointnet2.patch:144-174)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(idx)
+        ctx.n = features.shape[2]
+        return ops.grouping_operation(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        (idx,) = ctx.saved_tensors
+        return ops.grouping_operation_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+grouping_operation = GroupingOperation.apply
 
 _FUSED_MLP = [16, 16, 32]
 
@@ -79,6 +117,8 @@ class PointnetSAModuleMSG(nn.Module):
             self._out.append(spec[-1])
             spec[0] += 3
             self.mlps.append(_SharedMLP(spec))
+        self.differentiable = False              # True: forward() takes the composed, differentiable path whenever a
+                                                 # gradient is wanted, also for shapes the fused kernel covers
         self.fused = fused                       # one-kernel path (csrc/sa.hip); otherwise level-1 operators + dclr_linear
         self._cache = PackedCache()
         self._range_ok = None                    # weights key of the last checked split-f16 pass (ops.CHECK_RANGE)
@@ -144,7 +184,9 @@ class PointnetSAModuleMSG(nn.Module):
         if (0 if features is None else features.shape[1]) != self._in_feat:
             raise RuntimeError("expected {} feature channels, got {}".format(
                 self._in_feat, 0 if features is None else features.shape[1]))
-        if not self.fused:
+        if not self.fused or (torch.is_grad_enabled() and (xyz.requires_grad or (features is not None and features.requires_grad)
+                                                           or any(p.requires_grad for p in self.parameters()))
+                              and self.differentiable):
             return self._forward_composed(xyz, features)
         clouds = xyz if features is None else torch.cat((xyz, features.transpose(1, 2)), dim=2)
         rows = self.forward_rows(clouds.contiguous())
@@ -156,14 +198,26 @@ class PointnetSAModuleMSG(nn.Module):
         """The reference's own composition (QueryAndGroup + SharedMLP + max_pool2d) on the level-1 HIP operators."""
         xyz = xyz.contiguous()
         b = xyz.shape[0]
-        idx = ops.furthest_point_sample(xyz, self.npoint)
+        idx = ops.furthest_point_sample(xyz.detach(), self.npoint)
         xyz_t = xyz.transpose(1, 2).contiguous()
-        new_xyz_t = ops.gather_operation(xyz_t, idx)                               # (B, 3, npoint)
+        new_xyz_t = gather_operation(xyz_t, idx)                                   # (B, 3, npoint), differentiable
         new_xyz = new_xyz_t.transpose(1, 2).contiguous()
         feats = None if features is None else features.contiguous()
+        # Training (/root/reference/deepclr/engine/engines.py:57-84 differentiates through the module): gather / group
+        # go through the HIP operators and their HIP backward; the shared MLP and the max then stay in torch, whose
+        # autograd has their backward (rocBLAS GEMMs). Inference keeps dclr_linear with the max folded into the last layer.
+        train = torch.is_grad_enabled() and (xyz.requires_grad or (feats is not None and feats.requires_grad)
+                                             or any(p.requires_grad for p in self.parameters()))
         outs = []
-        for radius, nsample, layers in zip(self.radii, self.nsamples, self.packed_mlps()):
-            bq = ops.ball_query(radius, nsample, xyz, new_xyz)                     # (B, npoint, nsample) int32
+        for radius, nsample, layers, stack in zip(self.radii, self.nsamples, self.packed_mlps() if not train else
+                                                  [None] * len(self.radii), self.mlps):
+            bq = ops.ball_query(radius, nsample, xyz.detach(), new_xyz.detach())   # (B, npoint, nsample) int32
+            if train:
+                grouped = grouping_operation(xyz_t, bq) - new_xyz_t.unsqueeze(-1)  # (B, 3, npoint, nsample)
+                if feats is not None:
+                    grouped = torch.cat((grouped, grouping_operation(feats, bq)), dim=1)
+                outs.append(stack(grouped).max(dim=3).values)                      # 1x1 convs + ReLU, max over nsample
+                continue
             ns_p = (nsample + 63) // 64 * 64                                       # dclr_linear folds the max over blocks of 64 rows:
             if ns_p != nsample:                                                    # pad with repeats of the first neighbour (max unchanged)
                 bq = torch.cat((bq, bq[:, :, :1].expand(-1, -1, ns_p - nsample)), dim=2).contiguous()

@@ -73,6 +73,21 @@ int dclr_ball_query(int b, int n, int m, float radius, int nsample, const float 
 int dclr_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                       const int32_t *idx, float *out, dclr_stream_t stream);
 
+/* Replaces gather_points_grad_wrapper_fast(b, c, n, npoints, grad_out, idx, grad_points)
+ * (/root/reference/extern/pointnet2.patch:290-304): the backward of dclr_gather_points.
+ * grad_out (b,c,npoints) f32; idx (b,npoints) i32; grad_points (b,c,n) f32, zero-filled by the caller (the
+ * reference's autograd Function allocates it zeroed): grad_points[b,c,idx[b,j]] += grad_out[b,c,j]. */
+int dclr_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int32_t *idx,
+                            float *grad_points, dclr_stream_t stream);
+
+/* Replaces group_points_grad_wrapper_fast(b, c, n, npoints, nsample, grad_out, idx, grad_points)
+ * (/root/reference/extern/pointnet2.patch:144-158): the backward of dclr_group_points.
+ * grad_out (b,c,npoints,nsample); idx (b,npoints,nsample); grad_points (b,c,n), zero-filled by the caller:
+ * grad_points[b,c,idx[b,j,s]] += grad_out[b,c,j,s]. Runs of adjacent equal indices (a ball-query row repeats its
+ * first hit in every unused slot) are summed in registers and cost one atomic each. Out-of-range indices are ignored. */
+int dclr_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                           const int32_t *idx, float *grad_points, dclr_stream_t stream);
+
 /* Replaces torch_cluster.knn(x, y, k, batch_x, batch_y) for the equally sized, sorted batches
  * DeepCLR builds (/root/reference/deepclr/models/deepclr.py:149-155,164-166).
  * x (b*nx,3) candidates, y (b*ny,3) queries; row, col (b*ny*k) i64: row = global query index,

@@ -173,3 +173,122 @@ def test_ball_query_bit_exact_random_shapes(kind, n, m, radius, nsample, seed):
     want = oracle.ball_query(radius, nsample, xyz, new_xyz)
     got = ops.ball_query(radius, nsample, xyz.to(DEV), new_xyz.to(DEV)).cpu()
     assert torch.equal(got, want), (kind, n, m, radius, nsample)
+
+
+# ------------------------------------------------------------------------------------------------
+# backward of gather / group (reference wrappers pointnet2.patch:144-158, 290-304)
+# ------------------------------------------------------------------------------------------------
+def _group_ref(features, idx):
+    """CPU oracle of the index semantics: out[b, c, j, s] = features[b, c, idx[b, j, s]] in plain torch (autograd)."""
+    b, c, n = features.shape
+    flat = idx.reshape(b, 1, -1).expand(-1, c, -1).long()
+    return torch.gather(features, 2, flat).reshape(b, c, *idx.shape[1:])
+
+
+@pytest.mark.parametrize('kind,b,c,n,npoint,nsample,radius', [
+    ('dup', 2, 3, 1500, 64, 32, 0.25),        # duplicates: tie-heavy rows, long padding runs
+    ('grid', 2, 4, 2048, 100, 64, 1.1),       # lattice
+    ('kitti', 2, 1, 4096, 128, 512, 1.0),     # the model's own shapes: 1 feature channel, nsample 512 (mostly padding)
+    ('normal', 3, 7, 333, 50, 16, 0.6),
+    ('normal', 1, 2, 5000, 17, 1000, 3.0),    # nsample far beyond a wave: runs span many waves
+])
+def test_group_points_grad_matches_autograd_over_the_index_semantics(kind, b, c, n, npoint, nsample, radius):
+    xyz = _cloud(kind, b, n, seed=n + nsample)
+    fps = oracle.furthest_point_sample(xyz, npoint)
+    new_xyz = torch.gather(xyz, 1, fps.long()[:, :, None].expand(-1, -1, 3))
+    idx = oracle.ball_query(radius, nsample, xyz, new_xyz)                       # (b, npoint, nsample) with padding repeats
+    assert int((idx[:, :, 1:] == idx[:, :, :1]).sum()) > 0                         # the padding the kernel's run folding is for
+    rng = np.random.default_rng(7)
+    feats = torch.from_numpy(rng.normal(size=(b, c, n)).astype(np.float32))
+    grad_out = torch.from_numpy(rng.normal(size=(b, c, npoint, nsample)).astype(np.float32))
+    # float64 reference gradient (exact up to rounding of the final sum) and the f32 autograd result on the CPU
+    f64 = feats.double().requires_grad_(True)
+    _group_ref(f64, idx).backward(grad_out.double())
+    f32 = feats.clone().requires_grad_(True)
+    _group_ref(f32, idx).backward(grad_out)
+    # the HIP operator through its autograd Function
+    from deepclr_amd.pointnet2 import grouping_operation
+    f_dev = feats.to(DEV).requires_grad_(True)
+    out = grouping_operation(f_dev, idx.to(DEV))
+    assert torch.equal(out.detach().cpu(), _group_ref(feats, idx))               # forward: a pure copy
+    out.backward(grad_out.to(DEV))
+    got = f_dev.grad.cpu()
+    scale = float(f64.grad.abs().max())
+    assert float((got.double() - f64.grad).abs().max()) <= 2e-6 * max(1.0, scale) * np.sqrt(nsample)
+    # comparable to the CPU f32 scatter-add's own error against float64 (the run sums are tree sums: usually closer)
+    err_cpu = float((f32.grad.double() - f64.grad).abs().max())
+    err_hip = float((got.double() - f64.grad).abs().max())
+    assert err_hip <= 4 * err_cpu + 1e-5 * max(1.0, scale), (err_hip, err_cpu)
+    # points no row refers to receive exactly zero
+    untouched = torch.ones(b, n, dtype=torch.bool)
+    untouched.scatter_(1, idx.reshape(b, -1).long(), False)
+    assert float(got.abs().sum(dim=1)[untouched].max() if untouched.any() else 0.0) == 0.0
+    # level 1 through the C symbol accumulates INTO the caller's buffer (the reference zero-fills it first)
+    from deepclr_amd import lib
+    pre = torch.full((b, c, n), 0.5, device=DEV)
+    go_dev, idx_dev = grad_out.to(DEV), idx.to(DEV)                           # kept alive across the asynchronous call
+    lib.check(lib.load().dclr_group_points_grad(b, c, n, npoint, nsample, go_dev.data_ptr(), idx_dev.data_ptr(),
+                                                pre.data_ptr(), lib.stream_ptr()), 'group_points_grad')
+    torch.cuda.synchronize()
+    torch.testing.assert_close(pre.cpu() - 0.5, got, rtol=1e-4, atol=1e-4 * max(1.0, scale))
+
+
+@pytest.mark.parametrize('kind,b,c,n,npoint', [('kitti', 2, 3, 4096, 1024), ('dup', 3, 67, 300, 64), ('grid', 1, 5, 40, 100)])
+def test_gather_points_grad_matches_autograd_over_the_index_semantics(kind, b, c, n, npoint):
+    xyz = _cloud(kind, b, n, seed=n + npoint)
+    idx = oracle.furthest_point_sample(xyz, npoint)                              # npoint > n: index 0 repeats
+    rng = np.random.default_rng(3)
+    feats = torch.from_numpy(rng.normal(size=(b, c, n)).astype(np.float32))
+    grad_out = torch.from_numpy(rng.normal(size=(b, c, npoint)).astype(np.float32))
+    f64 = feats.double().requires_grad_(True)
+    _group_ref(f64, idx).backward(grad_out.double())
+    from deepclr_amd.pointnet2 import gather_operation
+    f_dev = feats.to(DEV).requires_grad_(True)
+    out = gather_operation(f_dev, idx.to(DEV))
+    assert torch.equal(out.detach().cpu(), _group_ref(feats, idx))
+    out.backward(grad_out.to(DEV))
+    torch.testing.assert_close(f_dev.grad.cpu().double(), f64.grad, rtol=1e-5, atol=1e-5 * max(1.0, float(f64.grad.abs().max())))
+
+
+def test_composed_set_abstraction_differentiates_through_the_hip_operators():
+    """The training step differentiates through the module (/root/reference/deepclr/engine/engines.py:57-84): with gradients
+    enabled the composed path gathers / groups through the HIP operators (and their HIP backward) and leaves the shared MLP
+    to torch. Gradients of a scalar loss w.r.t. the input features and the MLP weights against the same module evaluated
+    with plain torch indexing on the CPU (float64)."""
+    from deepclr_amd.pointnet2 import PointnetSAModuleMSG
+    rng = np.random.default_rng(11)
+    n, npoint, feat = 600, 48, 5
+    pts = rng.normal(size=(2, n, 3)); pts /= np.linalg.norm(pts, axis=2, keepdims=True); pts *= rng.uniform(0.3, 1.0, size=(2, n, 1))
+    xyz = torch.from_numpy(pts.astype(np.float32))
+    feats = torch.from_numpy(rng.normal(size=(2, feat, n)).astype(np.float32))
+    torch.manual_seed(4)
+    sam = PointnetSAModuleMSG(npoint=npoint, radii=[0.3, 0.6], nsamples=[8, 24], mlps=[[feat, 12, 20], [feat, 16, 8]],
+                              bn=False, use_xyz=True)
+    # CPU float64 twin: same indices (oracle), torch indexing, same weights
+    fps = oracle.furthest_point_sample(xyz, npoint)
+    new_xyz = torch.gather(xyz, 1, fps.long()[:, :, None].expand(-1, -1, 3))
+    f64 = feats.double().requires_grad_(True)
+    outs = []
+    twin = [[(u.conv.weight.detach().double().clone().requires_grad_(True), u.conv.bias.detach().double().clone().requires_grad_(True))
+             for u in stack] for stack in sam.mlps]
+    for (radius, nsample), layers in zip(zip(sam.radii, sam.nsamples), twin):
+        bq = oracle.ball_query(radius, nsample, xyz, new_xyz)
+        g = torch.cat((_group_ref(xyz.transpose(1, 2).double(), bq) - new_xyz.transpose(1, 2).double().unsqueeze(-1),
+                       _group_ref(f64, bq)), dim=1)
+        for w, bias in layers:
+            g = torch.relu(torch.einsum('oc,bcjs->bojs', w.reshape(w.shape[0], -1), g) + bias.view(1, -1, 1, 1))
+        outs.append(g.max(dim=3).values)
+    want = torch.cat(outs, dim=1)
+    probe = torch.from_numpy(rng.normal(size=tuple(want.shape))).double()
+    (want * probe).sum().backward()
+    # the module on the GPU, gradients enabled
+    sam = sam.to(DEV)
+    f_dev = feats.to(DEV).requires_grad_(True)
+    _, out = sam(xyz.to(DEV), f_dev)
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=1e-5)
+    (out * probe.float().to(DEV)).sum().backward()
+    torch.testing.assert_close(f_dev.grad.cpu().double(), f64.grad, rtol=1e-3, atol=1e-4 * float(f64.grad.abs().max()))
+    for stack, layers in zip(sam.mlps, twin):
+        for u, (w, bias) in zip(stack, layers):
+            torch.testing.assert_close(u.conv.weight.grad.cpu().double(), w.grad, rtol=1e-3, atol=1e-4 * float(w.grad.abs().max()))
+            torch.testing.assert_close(u.conv.bias.grad.cpu().double(), bias.grad, rtol=1e-3, atol=1e-4 * float(bias.grad.abs().max()))
