@@ -311,8 +311,8 @@ __device__ unsigned long long fps_bucket[16][6][3];   // per wave, per marks-in-
 #endif
 
 #ifndef FPS_J
-#define FPS_J 3           // samples a barrier round may accept (register kernel; the workspace kernel keeps 3)
-#endif
+#define FPS_J 4           // samples a barrier round of the table mode may accept (5 and 6 measured equal: the leader pays
+#endif                    // ~370 cycles per candidate for 0.4 more samples per round); per-wave candidates keep 3
 
 struct FpsCand {          // 16 bytes: one ds_write_b128 / ds_read_b128
     int32_t k;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         // 64 S points instead of 1024 stands in the way less often); no wave but the leader runs box tests (they were
         // 40 % of the instructions of a round); the groups are dealt out round-robin, so the handful a sample touches
         // are updated on different SIMDs; and the picks are not one serial chain of test -> pick -> test.
-        constexpr int J = FPS_J > 4 ? FPS_J : 4, NG = NW * G;
+        constexpr int J = FPS_J, NG = NW * G;
         static_assert(NG <= 64 && J <= 8, "one table entry per lane, one (j, i) pair of candidates per lane");
         __shared__ float gbox[64][8];                     // box of group q (min xyz, max xyz), written once
         __shared__ float4 rb_s[8];                        // the round's samples: x, y, z, -
@@ -847,7 +847,17 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 const uint32_t tk = lane < NG ? e0.y : 0xFFFFFFFFu;
                 int wid[J];
                 uint32_t mv[J];
+                unsigned long long reach[J];                              // groups candidate j can change (lane = group)
                 bool tie = false;
+                auto box_test = [&](int w) -> unsigned long long {
+                    const float sx = __uint_as_float(__builtin_amdgcn_readlane((int)e1.x, w));
+                    const float sy = __uint_as_float(__builtin_amdgcn_readlane((int)e1.y, w));
+                    const float sz = __uint_as_float(__builtin_amdgcn_readlane((int)e1.z, w));
+                    const float lbv = fps_box_lower_bound(blo.x, blo.y, blo.z, blo.w, bhi.x, bhi.y, sx, sy, sz);
+                    // (its own group is always marked: with b_g = 0, an exhausted cloud, the box test marks nothing, and the
+                    // workers count the accepted samples by their non-empty masks)
+                    return __ballot(lane < NG && lbv < __uint_as_float(val)) | (1ull << w);
+                };
 #pragma unroll
                 for (int j = 0; j < J; ++j) {                             // J chained wave maxima: candidates in value order
                     mv[j] = dclr_wave_max_u32(v);
@@ -855,6 +865,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                     tie = tie || (holders & (holders - 1)) != 0;
                     wid[j] = __builtin_ctzll(holders);
                     v = lane == wid[j] ? 0u : v;
+                    // the box test of candidate j sits here so that its arithmetic fills the wait states of the next
+                    // reduction's cross-lane steps (one straight run of instructions; a rejected candidate's mask is dropped)
+                    reach[j] = box_test(wid[j]);
                 }
                 if (tie) {
                     // two entries share a value (duplicate points, lattices, an exhausted cloud): again, by (value, key).
@@ -866,8 +879,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                         const uint32_t mx = dclr_wave_max_u32(v);
                         const uint32_t kmin = dclr_wave_min_u32(v == mx ? tk : 0xFFFFFFFFu);
                         const int w = __builtin_ctzll(__ballot(v == mx && tk == kmin));
+                        const unsigned long long rw = box_test(w);
 #pragma unroll
-                        for (int u = 0; u < J; ++u) { if (u == j) { wid[u] = w; mv[u] = mx; } }
+                        for (int u = 0; u < J; ++u) { if (u == j) { wid[u] = w; mv[u] = mx; reach[u] = rw; } }
                         v = lane == w ? 0u : v;
                     }
                 }
@@ -897,18 +911,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                     open = open && ok;
                     cnt += open ? 1 : 0;
                 }
-                // which groups can candidate j change? lane = group (all J computed, the masks of the rejected ones are dropped)
                 unsigned long long am[J];
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    const float sx = __uint_as_float(__builtin_amdgcn_readlane((int)e1.x, wid[j]));
-                    const float sy = __uint_as_float(__builtin_amdgcn_readlane((int)e1.y, wid[j]));
-                    const float sz = __uint_as_float(__builtin_amdgcn_readlane((int)e1.z, wid[j]));
-                    const float lbv = fps_box_lower_bound(blo.x, blo.y, blo.z, blo.w, bhi.x, bhi.y, sx, sy, sz);
-                    // (its own group is always marked: with b_g = 0, an exhausted cloud, the box test marks nothing, and the
-                    // workers count the accepted samples by their non-empty masks)
-                    am[j] = j < cnt ? (__ballot(lane < NG && lbv < __uint_as_float(val)) | (1ull << wid[j])) : 0ull;
-                }
+                for (int j = 0; j < J; ++j) am[j] = j < cnt ? reach[j] : 0ull;
 #ifdef FPS_DEBUG
                 if (blockIdx.x == 0) {
                     unsigned long long all = 0;
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         // p3 after p1, p2, and so on. All waves evaluate the test on the same 16 published entries, so they agree
         // without another exchange; then each applies the accepted samples one after the other. The exchange
         // (select, publish, barrier, combine) -- two thirds of a round -- is paid once per batch of samples.
-        constexpr int J = FPS_J;
+        constexpr int J = 3;
         if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
         __syncthreads();
         float pcx[J] = {cx}, pcy[J] = {cy}, pcz[J] = {cz};

@@ -47,6 +47,8 @@ MODES = {
     'ring': ['--clouds', 'ring'],                                           # LiDAR-density clouds: nsample caps reached
     'ring_strict': ['--clouds', 'ring', '--strict', '--steps', '200', '--warmup', '20'],
     'ring_c5': ['--config', 'c5', '--clouds', 'ring'],
+    'c4': ['--config', 'c4'],
+    'c5': ['--config', 'c5'],
     'latency': ['--latency', '--steps', '50', '--warmup', '10'],            # B = 1, one pair per predict call
     'latency_ring': ['--latency', '--clouds', 'ring', '--steps', '50', '--warmup', '10'],
 }
