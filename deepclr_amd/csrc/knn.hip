@@ -41,7 +41,7 @@ struct KnnRowSource {            // feature rows F: xyz at columns 64..66 of a 6
 // k-round selection latency.
 template <int CPL, typename Src, typename OutFn>
 __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, int nx, const Src &query,
-                                          size_t query_cloud, int ny, int k, OutFn out) {
+                                          size_t query_cloud, int ny, int k, int block, OutFn out) {
     extern __shared__ float knn_lds[];                      // x[nxp] y[nxp] z[nxp], nxp = 64 * CPL
     constexpr int NXP = 64 * CPL;
     float *sx = knn_lds, *sy = knn_lds + NXP, *sz = knn_lds + 2 * NXP;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
         sx[i] = x; sy[i] = y; sz[i] = z;
     }
     __syncthreads();
-    const int q0 = (blockIdx.x * KNN_WAVES + wave) * KNN_QRUN;
+    const int q0 = (block * KNN_WAVES + wave) * KNN_QRUN;
 #pragma unroll 1
     for (int q = q0; q < q0 + KNN_QRUN && q < ny; ++q) {
         float qx, qy, qz;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_xyz_kernel(int nx, int ny,
                                                                  int64_t *__restrict__ col) {
     const size_t bi = blockIdx.y;
     KnnXyzSource cs{x}, qs{y};
-    knn_block<CPL>(cs, bi, nx, qs, bi, ny, k, [&](int q, int s, int ci) {
+    knn_block<CPL>(cs, bi, nx, qs, bi, ny, k, (int)blockIdx.x, [&](int q, int s, int ci) {
         const size_t gq = bi * ny + q;
         row[gq * k + s] = ci < 0 ? -1 : (int64_t)gq;
         col[gq * k + s] = ci < 0 ? -1 : (int64_t)(bi * nx + ci);
@@ -205,9 +205,18 @@ template <int CPL>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_rows_kernel(int pairs, int npoint, int k,
                                                                   const float *__restrict__ f_rows,
                                                                   int32_t *__restrict__ knn_idx) {
-    const size_t bi = blockIdx.y;
+    // (the blocks of one pair stage the same candidate cloud: with a multiple of 8 pairs a pair's blocks are given ids
+    // that the hardware deals to ONE XCD -- block ids b and b + 8 share an L2 -- instead of all eight; speed only)
+    size_t bi = blockIdx.y;
+    int bx = blockIdx.x;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned linear = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = linear & 7u, i = linear >> 3;
+        bi = (size_t)(i / gridDim.x) * 8u + xcd;
+        bx = (int)(i % gridDim.x);
+    }
     KnnRowSource src{f_rows};
-    knn_block<CPL>(src, bi + pairs, npoint, src, bi, npoint, k, [&](int q, int s, int ci) {
+    knn_block<CPL>(src, bi + pairs, npoint, src, bi, npoint, k, bx, [&](int q, int s, int ci) {
         knn_idx[(bi * npoint + q) * k + s] = ci;
     });
 }

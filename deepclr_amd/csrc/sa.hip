@@ -70,6 +70,8 @@ __shared__ float4 sa_tile[1][SA_TILE];
 __shared__ uint32_t sa_ring[SA_WAVES][SA_MAX_SCALES][SA_RING];
 __shared__ __attribute__((aligned(16))) float sa_obuf[SA_WAVES][64 * 4 + 64];   // drain staging: 64 inputs (float4) + 64 centroid tags
 __shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
+__shared__ float sa_c16[SA_WAVES * SA_CPW][4];      // the workgroup's 16 centroids (groups path: waves pull them one at a time)
+__shared__ int sa_next;                              // next centroid of the workgroup to be taken
 
 // running maxima per (wave, scale, centroid slot, channel): non-negative floats, compared as u32
 __shared__ uint32_t sa_acc[SA_WAVES][SA_MAX_SCALES][SA_CPW][SA_OUT];
@@ -279,27 +281,43 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                                                                float *__restrict__ out_rows,
                                                                int32_t *__restrict__ counts) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t bi = blockIdx.y;
-    const int j0 = (blockIdx.x * SA_WAVES + wave) * SA_CPW;          // this wave's first centroid
+    // Workgroup -> (cloud, centroid block). The workgroups of ONE cloud all scan that cloud's groups (256 KB of sorted
+    // points): dealt round-robin over the 8 XCDs as the hardware does with consecutive block ids, every XCD's L2 fetches
+    // every cloud (measured 443 MB per 160-cloud launch against 88 MB of clouds + groups + rows). With a multiple of 8
+    // clouds, block L goes to cloud (L / 8 / blocks_per_cloud) * 8 + L % 8: a cloud's blocks share one L2. Speed only --
+    // any placement gives the same rows (MI355X_MICROARCH.md: block b and b + 8 share an XCD, not guaranteed).
+    size_t bi = blockIdx.y;
+    int bx = blockIdx.x;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned linear = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned xcd = linear & 7u, i = linear >> 3;
+        bi = (size_t)(i / gridDim.x) * 8u + xcd;
+        bx = (int)(i % gridDim.x);
+    }
+    const int j0 = (bx * SA_WAVES + wave) * SA_CPW;                  // this wave's first centroid
     const float *cloud = clouds + bi * (size_t)prm.n * C;
 
-    // centroids of this wave; a slot past the end of the cloud's centroid list starts "full" so the
-    // sweep never records a hit for it
-    float ccx[SA_CPW], ccy[SA_CPW], ccz[SA_CPW];
+    // The workgroup's 16 centroids go to LDS once. Without groups (exhaustive sweep) wave w keeps centroids 4 w .. 4 w + 3
+    // for the whole kernel; with groups the waves PULL centroids one at a time (sa_next): a workgroup lives as long as its
+    // slowest wave, and with a fixed four centroids per wave that was the wave that drew the crowded ones (LiDAR-density
+    // clouds: per-wave cycles median 61 k, p90 124 k -- the maximum of four is twice the mean).
+    const int jw0 = bx * SA_WAVES * SA_CPW;                          // the workgroup's first centroid
+    const int n_wg = prm.npoint - jw0 < SA_WAVES * SA_CPW ? prm.npoint - jw0 : SA_WAVES * SA_CPW;
+    if (tid < SA_WAVES * SA_CPW) {
+        const int jc = tid < n_wg ? jw0 + tid : prm.npoint - 1;
+        const float4 q = sa_load_point<C>(cloud, fps_idx[bi * prm.npoint + jc]);
+        sa_c16[tid][0] = q.x; sa_c16[tid][1] = q.y; sa_c16[tid][2] = q.z; sa_c16[tid][3] = 0.f;
+    }
+    if (tid == 0) sa_next = 0;
     int cnt[SA_CPW][SA_MAX_SCALES];
-    const int n_live = prm.npoint - j0 < SA_CPW ? prm.npoint - j0 : SA_CPW;
+    int jrow[SA_CPW];                                                // centroid (row) index of slot c, -1: slot unused
+    const int n_live = prm.npoint - j0 < SA_CPW ? (prm.npoint - j0 > 0 ? prm.npoint - j0 : 0) : SA_CPW;
 #pragma unroll
     for (int c = 0; c < SA_CPW; ++c) {
         const bool live = c < n_live;
-        const int jc = live ? j0 + c : prm.npoint - 1;
-        const int ck = __builtin_amdgcn_readfirstlane(fps_idx[bi * prm.npoint + jc]);
-        const float4 q = sa_load_point<C>(cloud, ck);
-        ccx[c] = q.x; ccy[c] = q.y; ccz[c] = q.z;                    // wave-uniform values kept in VGPRs
-        if (lane == 0) {
-            sa_cxyz[wave][c][0] = q.x; sa_cxyz[wave][c][1] = q.y; sa_cxyz[wave][c][2] = q.z; sa_cxyz[wave][c][3] = 0.f;
-        }
-        cnt[c][0] = live ? 0 : prm.nsample[0];
-        cnt[c][1] = live ? 0 : prm.nsample[1];
+        jrow[c] = live ? j0 + c : -1;
+        cnt[c][0] = live ? 0 : prm.nsample[0];                       // a slot past the end starts "full": the sweep never
+        cnt[c][1] = live ? 0 : prm.nsample[1];                       // records a hit for it
     }
 
     int qhead[SA_MAX_SCALES] = {0, 0}, qn[SA_MAX_SCALES] = {0, 0};
@@ -311,12 +329,28 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
             for (int i = tid; i < mlp_floats; i += SA_WAVES * 64) sa_w[s][i] = prm.mlp[s][i];
     }
     __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SA_CPW; ++c)
+        if (lane < 4) sa_cxyz[wave][c][lane] = sa_c16[wave * SA_CPW + c][lane];
 
 #ifdef SA_DEBUG
     if (lane == 0) { sa_dbg_l[wave][0] = 0; sa_dbg_l[wave][1] = 0; }
     unsigned long long t_begin, t_fast = 0, t_drain = 0, n_drain = 0, t_sweep = 0;
     SA_STAMP(t_begin);
 #endif
+    // rows of the slots in use: the pooled features, the centroid, the counts; then the slots are free again
+    auto write_rows = [&]() {
+#pragma unroll
+        for (int c = 0; c < SA_CPW; ++c) {
+            if (jrow[c] < 0) continue;                                // wave-uniform
+            float *orow = out_rows + (bi * prm.npoint + jrow[c]) * DCLR_F_STRIDE;
+            // lane = s * 32 + channel; columns of an absent scale stay zero
+            orow[lane] = (lane >> 5) < prm.n_scales ? __uint_as_float(sa_acc[wave][lane >> 5][c][lane & 31]) : 0.f;
+            if (lane < 4) orow[64 + lane] = lane < 3 ? sa_cxyz[wave][c][lane] : 0.f;
+            if (counts && lane < prm.n_scales)
+                counts[(bi * prm.npoint + jrow[c]) * prm.n_scales + lane] = lane == 0 ? cnt[c][0] : cnt[c][1];
+        }
+    };
     auto drain_all = [&](bool final_pass) {
 #pragma unroll
         for (int s = 0; s < SA_MAX_SCALES; ++s) {
@@ -338,29 +372,68 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         }
     };
 
+    uint32_t done = 0;                                     // bit c: slot c was finished on the groups path, counts in sa_tot
+    // The slots in use are complete: counts, the published zero-hit behaviour, the last (partial) drains, the rows.
+    auto finish_slots = [&]() {
+#pragma unroll
+        for (int c = 0; c < SA_CPW; ++c)
+            if ((done >> c) & 1u) { cnt[c][0] = sa_tot[wave][c][0]; cnt[c][1] = sa_tot[wave][c][1]; }
+        // published behaviour for a centroid without any hit: its (zero-filled) index row means point 0
+#pragma unroll
+        for (int c = 0; c < SA_CPW; ++c)
+#pragma unroll
+            for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                if (s >= prm.n_scales) break;
+                if (jrow[c] >= 0 && cnt[c][s] == 0) {
+                    if (lane == 0) sa_ring[wave][s][(qhead[s] + qn[s]) & (SA_RING - 1)] = (uint32_t)c << 16;
+                    qn[s] += 1;
+                }
+            }
+        drain_all(true);
+        write_rows();
+    };
+
     // ---- fast path over the sampling kernel's spatial groups ---------------------------------------
-    // Runtime loop over the wave's centroids (coordinates and counts through LDS) to keep one small
-    // copy of the code; `done` bit c = centroid slot c is finished, its true counts are in sa_tot.
-    uint32_t done = 0;
+    // The waves of the workgroup pull its centroids one at a time; a wave keeps up to SA_CPW of them in its slots
+    // (coordinates, counts and running maxima through LDS, tagged by slot in the ring) and finishes the slots -- last
+    // drains, rows -- when all are taken and once at the end.
     const bool need_sweep = prm.group_pts == nullptr;
     if (prm.group_pts != nullptr) {
+#pragma unroll
+        for (int u = 0; u < SA_CPW; ++u) { jrow[u] = -1; cnt[u][0] = 0; cnt[u][1] = 0; }
         const float4 *gp = prm.group_pts + bi * (size_t)prm.n_groups * prm.group_size;
         // lane g owns the boxes of groups g, 64 + g, ... (NCH chunks of 64 groups: 1 for the register sampler's <= 64
         // groups, 2 / 4 for the workspace sampler's 128 / 256)
         // (with one chunk the boxes stay in registers for the wave's four centroids; with 2 / 4 chunks they are re-read per
         // centroid -- 6 L2-resident loads per chunk -- rather than held across the drain calls: 128 registers per wave)
-        auto load_box = [&](int ch, float (&bx)[6]) {
+        auto load_box = [&](int ch, float (&bb)[6]) {
             const bool have = ch * 64 + lane < prm.n_groups;
             const float *gb = prm.group_box + (bi * prm.n_groups + (have ? ch * 64 + lane : 0)) * 8;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { bx[a] = have ? gb[a] : 3.0e38f; bx[3 + a] = have ? gb[3 + a] : -3.0e38f; }
+            for (int a = 0; a < 3; ++a) { bb[a] = have ? gb[a] : 3.0e38f; bb[3 + a] = have ? gb[3 + a] : -3.0e38f; }
         };
         float box0[6];
         if constexpr (NCH == 1) load_box(0, box0);
         const int slices = prm.group_size / 64;
+        int c = 0;                                             // next free slot
 #pragma unroll 1
-        for (int c = 0; c < n_live; ++c) {
-            const float cx = sa_cxyz[wave][c][0], cy = sa_cxyz[wave][c][1], cz = sa_cxyz[wave][c][2];
+        for (;;) {
+            int pulled = 0;
+            if (lane == 0) pulled = atomicAdd(&sa_next, 1);
+            pulled = __builtin_amdgcn_readfirstlane(pulled);
+            if (pulled >= n_wg) break;
+            if (c == SA_CPW) {                                 // all slots taken: finish them, start over
+                finish_slots();
+                for (int i = lane; i < SA_MAX_SCALES * SA_CPW * SA_OUT; i += 64) (&sa_acc[wave][0][0][0])[i] = 0u;
+#pragma unroll
+                for (int u = 0; u < SA_CPW; ++u) { jrow[u] = -1; cnt[u][0] = 0; cnt[u][1] = 0; }
+                done = 0;
+                c = 0;
+            }
+            if (lane < 4) sa_cxyz[wave][c][lane] = sa_c16[pulled][lane];
+#pragma unroll
+            for (int u = 0; u < SA_CPW; ++u) jrow[u] = u == c ? jw0 + pulled : jrow[u];
+            const float cx = sa_c16[pulled][0], cy = sa_c16[pulled][1], cz = sa_c16[pulled][2];
             uint64_t gm[NCH];          // groups the largest ball can reach, per chunk (an absent group's bound is +inf)
             if constexpr (NCH == 1) {
                 gm[0] = __ballot(sa_box_lower_bound(box0[0], box0[1], box0[2], box0[3], box0[4], box0[5], cx, cy, cz) <
@@ -368,9 +441,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
             } else {
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
-                    float bx[6];
-                    load_box(ch, bx);
-                    gm[ch] = __ballot(sa_box_lower_bound(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], cx, cy, cz) < prm.radius2_max);
+                    float bb[6];
+                    load_box(ch, bb);
+                    gm[ch] = __ballot(sa_box_lower_bound(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], cx, cy, cz) < prm.radius2_max);
                 }
             }
             // One pass: neighbours are staged for the MLP as they are found (any order) and counted. If a cap
@@ -543,11 +616,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
             if (qn[0] >= 64 || qn[1] >= 64) drain_all(false);
             done |= 1u << c;
             if (lane == 0) { sa_tot[wave][c][0] = n1[0]; sa_tot[wave][c][1] = n1[1]; }
+            ++c;
         }
     }
-#pragma unroll
-    for (int c = 0; c < SA_CPW; ++c)
-        if ((done >> c) & 1u) { cnt[c][0] = prm.nsample[0]; cnt[c][1] = prm.nsample[1]; }   // closed for the sweep
 
 #ifdef SA_DEBUG
     { unsigned long long t1; SA_STAMP(t1); t_fast = t1 - t_begin; }
@@ -557,6 +628,12 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
 #ifdef SA_DEBUG
         unsigned long long w0; SA_STAMP(w0);
 #endif
+        float ccx[SA_CPW], ccy[SA_CPW], ccz[SA_CPW];                    // this wave's centroids (wave-uniform)
+#pragma unroll
+        for (int c = 0; c < SA_CPW; ++c) {
+            const int src = wave * SA_CPW + c;
+            ccx[c] = sa_c16[src][0]; ccy[c] = sa_c16[src][1]; ccz[c] = sa_c16[src][2];
+        }
         const int n_tiles = (prm.n + SA_TILE - 1) / SA_TILE;
         constexpr int PER_THREAD = SA_TILE / (SA_WAVES * 64);           // points staged per thread
         float4 stage[PER_THREAD];
@@ -618,33 +695,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         { unsigned long long w1; SA_STAMP(w1); t_sweep = w1 - w0; }
 #endif
     }
-#pragma unroll
-    for (int c = 0; c < SA_CPW; ++c)
-        if ((done >> c) & 1u) { cnt[c][0] = sa_tot[wave][c][0]; cnt[c][1] = sa_tot[wave][c][1]; }
-
-    // published behaviour for a centroid without any hit: its (zero-filled) index row means point 0
-#pragma unroll
-    for (int c = 0; c < SA_CPW; ++c)
-#pragma unroll
-        for (int s = 0; s < SA_MAX_SCALES; ++s) {
-            if (s >= prm.n_scales) break;
-            if (c < n_live && cnt[c][s] == 0) {
-                if (lane == 0) sa_ring[wave][s][(qhead[s] + qn[s]) & (SA_RING - 1)] = (uint32_t)c << 16;
-                qn[s] += 1;
-            }
-        }
-    drain_all(true);
-
-#pragma unroll
-    for (int c = 0; c < SA_CPW; ++c) {
-        if (c >= n_live) break;
-        float *orow = out_rows + (bi * prm.npoint + j0 + c) * DCLR_F_STRIDE;
-        // lane = s * 32 + channel; columns of an absent scale stay zero
-        orow[lane] = (lane >> 5) < prm.n_scales ? __uint_as_float(sa_acc[wave][lane >> 5][c][lane & 31]) : 0.f;
-        if (lane < 4) orow[64 + lane] = lane == 0 ? ccx[c] : (lane == 1 ? ccy[c] : (lane == 2 ? ccz[c] : 0.f));
-        if (counts && lane < prm.n_scales)
-            counts[(bi * prm.npoint + j0 + c) * prm.n_scales + lane] = lane == 0 ? cnt[c][0] : cnt[c][1];
-    }
+    finish_slots();
 #ifdef SA_DEBUG
     if (lane == 0) {
         unsigned long long t_end; SA_STAMP(t_end);
