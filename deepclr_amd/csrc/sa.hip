@@ -72,6 +72,9 @@ __shared__ __attribute__((aligned(16))) float sa_obuf[SA_WAVES][64 * 4 + 64];   
 __shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
 __shared__ float sa_c16[SA_WAVES * SA_CPW][4];      // the workgroup's 16 centroids (groups path: waves pull them one at a time)
 __shared__ int sa_next;                              // next centroid of the workgroup to be taken
+__shared__ int sa_crowd[SA_WAVES * SA_CPW];          // crowded centroids of the workgroup (redone by the four waves together)
+__shared__ int sa_ncrowd;
+__shared__ int sa_cnt[SA_MAX_SCALES];                // their hit counts, summed over the waves
 
 // running maxima per (wave, scale, centroid slot, channel): non-negative floats, compared as u32
 __shared__ uint32_t sa_acc[SA_WAVES][SA_MAX_SCALES][SA_CPW][SA_OUT];
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         const float4 q = sa_load_point<C>(cloud, fps_idx[bi * prm.npoint + jc]);
         sa_c16[tid][0] = q.x; sa_c16[tid][1] = q.y; sa_c16[tid][2] = q.z; sa_c16[tid][3] = 0.f;
     }
-    if (tid == 0) sa_next = 0;
+    if (tid == 0) { sa_next = 0; sa_ncrowd = 0; }
     int cnt[SA_CPW][SA_MAX_SCALES];
     int jrow[SA_CPW];                                                // centroid (row) index of slot c, -1: slot unused
     const int n_live = prm.npoint - j0 < SA_CPW ? (prm.npoint - j0 > 0 ? prm.npoint - j0 : 0) : SA_CPW;
@@ -512,111 +515,183 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
             }
             if (over || n1[0] > prm.nsample[0] || (prm.n_scales > 1 && n1[1] > prm.nsample[1])) {
                 // Crowded centroid: the ring would overflow (> ~450 neighbours) or a cap is exceeded, and then INDEX order
-                // decides which nsample neighbours count. Take its entries back (none has been drained) and redo it on
-                // the same candidate groups -- they hold every hit, in any order:
-                //   1. exact hit counts per scale (known already unless the pass above stopped early);
-                //   2. per scale over its cap: the nsample-th smallest point index T among its hits, by a two-level
-                //      radix select on the 16-bit index (256-bin histograms in this wave's drain staging buffer);
-                //   3. stage the hits with index <= T, draining whenever the ring fills (their membership is final).
-                // Rare (LiDAR near field), wave-local and exact; the exhaustive in-order sweep below is left to calls
-                // without groups. Before: one such centroid sent its whole workgroup through all N points.
+                // decides which nsample neighbours count. Its entries are taken back (none has been drained) and the
+                // centroid goes on the workgroup's list: once the other centroids are done, the four waves redo it TOGETHER.
                 qn[0] = q0[0]; qn[1] = q0[1];
-                uint64_t ghit[NCH];                                    // groups in which a scan found a hit
-                auto scan = [&](auto &&per_slice) {
-#pragma unroll 1
-                    for (int chn = 0; chn < NCH; ++chn) {
-                        ghit[chn] = 0;
-#pragma unroll 1
-                        for (uint64_t mm = gm[chn]; mm != 0; mm &= mm - 1) {
-                            const float4 *pg = gp + (size_t)(chn * 64 + __builtin_ctzll(mm)) * prm.group_size + lane;
-                            constexpr int SB = NCH >= 4 ? 2 : 4;       // slices per round trip (register budget: 128 per wave)
-#pragma unroll 1
-                            for (int it0 = 0; it0 < slices; it0 += SB) {
-                                float4 qq[SB];
+                if (lane == 0) sa_crowd[atomicAdd(&sa_ncrowd, 1)] = pulled;
 #pragma unroll
-                                for (int it = 0; it < SB; ++it) qq[it] = pg[(it0 + it < slices ? it0 + it : slices - 1) * 64];
-#pragma unroll
-                                for (int it = 0; it < SB; ++it) {
-                                    if (it0 + it >= slices) break;     // wave-uniform
-                                    const float d2 = dclr_sqdist(cx, cy, cz, qq[it].x, qq[it].y, qq[it].z);
-                                    if (__ballot(d2 < prm.radius2_max) == 0) continue;
-                                    ghit[chn] |= mm & (0 - mm);                // lowest set bit = this group
-                                    per_slice(d2, __float_as_uint(qq[it].w) & 0xFFFFu);
-                                }
-                            }
-                        }
-                    }
-                };
-                if (over) {
-                    n1[0] = n1[1] = 0;
-                    scan([&](float d2, uint32_t) {
-                        n1[0] += __builtin_popcountll(__ballot(d2 < prm.radius2[0]));
-                        if (prm.n_scales > 1) n1[1] += __builtin_popcountll(__ballot(d2 < prm.radius2[1]));
-                    });
-                    // the later passes visit only the groups that hold a hit (a box can reach into the ball without one)
-#pragma unroll
-                    for (int chn = 0; chn < NCH; ++chn) gm[chn] = ghit[chn];
-                }
-                uint32_t thr[SA_MAX_SCALES] = {0xFFFFu, 0xFFFFu};
-                uint32_t *hist = reinterpret_cast<uint32_t *>(sa_obuf[wave]);          // 256 bins (320 words available)
-#pragma unroll 1
-                for (int s = 0; s < prm.n_scales; ++s) {
-                    if (n1[s] <= prm.nsample[s]) continue;
-                    uint32_t prefix = 0;                     // high byte of T once known
-                    int need = prm.nsample[s];               // rank of T among the hits still in play (1-based)
-#pragma unroll 1
-                    for (int level = 0; level < 2; ++level) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) hist[4 * lane + u] = 0u;
-                        const float r2 = prm.radius2[s];
-                        scan([&](float d2, uint32_t k) {
-                            const bool in = d2 < r2 && (level == 0 || (k >> 8) == prefix);
-                            if (in) atomicAdd(&hist[level == 0 ? (k >> 8) : (k & 255u)], 1u);
-                        });
-                        // lane l owns bins 4 l .. 4 l + 3; exclusive prefix over the lanes, then inside the lane
-                        uint32_t cb[4], mine = 0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { cb[u] = hist[4 * lane + u]; mine += cb[u]; }
-                        uint32_t incl = mine;
-#pragma unroll
-                        for (int off = 1; off < 64; off <<= 1) {
-                            const uint32_t up = __shfl_up(incl, off);
-                            if (lane >= off) incl += up;
-                        }
-                        const uint32_t excl = incl - mine;
-                        const int wl = __builtin_ctzll(__ballot(excl < (uint32_t)need && (uint32_t)need <= incl));
-                        uint32_t run = excl, bin = 0, before = 0;
-                        bool found = false;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (!found && run + cb[u] >= (uint32_t)need) { bin = 4 * lane + u; before = run; found = true; }
-                            run += cb[u];
-                        }
-                        const uint32_t wbin = (uint32_t)__builtin_amdgcn_readlane((int)bin, wl);
-                        need -= (int)__builtin_amdgcn_readlane((int)before, wl);
-                        if (level == 0) prefix = wbin; else thr[s] = (prefix << 8) | wbin;
-                    }
-                    n1[s] = prm.nsample[s];
-                }
-                scan([&](float d2, uint32_t k) {
-#pragma unroll
-                    for (int s = 0; s < SA_MAX_SCALES; ++s) {
-                        if (s >= prm.n_scales) break;
-                        const bool hit = d2 < prm.radius2[s] && k <= thr[s];
-                        const uint64_t mask = __ballot(hit);
-                        if (mask != 0) {
-                            if (qn[s] + 64 > SA_RING) drain_all(false);           // leaves < 64 entries in each ring
-                            const int pre = (int)dclr_lanemask_lt_popc(mask);
-                            if (hit) sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = ((uint32_t)c << 16) | k;
-                            qn[s] += __builtin_popcountll(mask);
-                        }
-                    }
-                });
+                for (int u = 0; u < SA_CPW; ++u) jrow[u] = u == c ? -1 : jrow[u];
+                continue;                                      // the slot is free again
             }
             if (qn[0] >= 64 || qn[1] >= 64) drain_all(false);
             done |= 1u << c;
             if (lane == 0) { sa_tot[wave][c][0] = n1[0]; sa_tot[wave][c][1] = n1[1]; }
             ++c;
+        }
+        // ---- crowded centroids, the four waves together ------------------------------------------------------------
+        // Every hit of such a centroid lies in its candidate groups (any order); the waves split those groups
+        // (every fourth one each) and
+        //   1. count the hits per scale (shared counters);
+        //   2. per scale over its cap find the nsample-th smallest point index T among the hits by a two-level radix
+        //      select on the 16-bit index (one shared 256-bin histogram per level: the point indices of a cloud are
+        //      distinct, so the second level lands on T exactly);
+        //   3. stage their share of the hits with index <= T in their own ring (slot 0), draining whenever it fills;
+        //   4. wave 0 folds the four partial maxima and writes the row.
+        // Exact, and one crowded centroid costs its workgroup a quarter of what it cost the wave that drew it (the
+        // LiDAR near field: 2-6 % of the centroids, each worth 10-20 ordinary ones). Round 2 sent the whole workgroup
+        // through all N points instead.
+        finish_slots();                                        // the ordinary centroids of this wave: last drains, rows
+        done = 0;
+#pragma unroll
+        for (int u = 0; u < SA_CPW; ++u) { jrow[u] = -1; cnt[u][0] = 0; cnt[u][1] = 0; }
+        __syncthreads();
+        const int n_crowd = sa_ncrowd;                         // the same in every wave from here on
+        uint32_t *shist = reinterpret_cast<uint32_t *>(&sa_tile[0][0]);       // 256 shared bins (the sweep's tile is idle here)
+#pragma unroll 1
+        for (int kc = 0; kc < n_crowd; ++kc) {
+            const int pc = sa_crowd[kc];
+            const float cx = sa_c16[pc][0], cy = sa_c16[pc][1], cz = sa_c16[pc][2];
+            uint64_t gm[NCH];
+            if constexpr (NCH == 1) {
+                gm[0] = __ballot(sa_box_lower_bound(box0[0], box0[1], box0[2], box0[3], box0[4], box0[5], cx, cy, cz) <
+                                 prm.radius2_max);
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    float bb[6];
+                    load_box(ch, bb);
+                    gm[ch] = __ballot(sa_box_lower_bound(bb[0], bb[1], bb[2], bb[3], bb[4], bb[5], cx, cy, cz) < prm.radius2_max);
+                }
+            }
+            // this wave's share of the candidate groups: every SA_WAVES-th one, then only those in which a scan found a hit
+            {
+                int turn = 0;
+#pragma unroll
+                for (int chn = 0; chn < NCH; ++chn) {
+                    uint64_t keep = 0;
+                    for (uint64_t mm = gm[chn]; mm != 0; mm &= mm - 1) {
+                        if ((turn++ & (SA_WAVES - 1)) == wave) keep |= mm & (0 - mm);
+                    }
+                    gm[chn] = keep;
+                }
+            }
+            uint64_t ghit[NCH];
+            auto scan = [&](auto &&per_slice) {
+#pragma unroll 1
+                for (int chn = 0; chn < NCH; ++chn) {
+                    ghit[chn] = 0;
+#pragma unroll 1
+                    for (uint64_t mm = gm[chn]; mm != 0; mm &= mm - 1) {
+                        const float4 *pg = gp + (size_t)(chn * 64 + __builtin_ctzll(mm)) * prm.group_size + lane;
+                        constexpr int SB = NCH >= 4 ? 2 : 4;           // slices per round trip (register budget: 128 per wave)
+#pragma unroll 1
+                        for (int it0 = 0; it0 < slices; it0 += SB) {
+                            float4 qq[SB];
+#pragma unroll
+                            for (int it = 0; it < SB; ++it) qq[it] = pg[(it0 + it < slices ? it0 + it : slices - 1) * 64];
+#pragma unroll
+                            for (int it = 0; it < SB; ++it) {
+                                if (it0 + it >= slices) break;         // wave-uniform
+                                const float d2 = dclr_sqdist(cx, cy, cz, qq[it].x, qq[it].y, qq[it].z);
+                                if (__ballot(d2 < prm.radius2_max) == 0) continue;
+                                ghit[chn] |= mm & (0 - mm);            // lowest set bit = this group
+                                per_slice(d2, __float_as_uint(qq[it].w) & 0xFFFFu);
+                            }
+                        }
+                    }
+                }
+            };
+            // 1. counts
+            if (tid < SA_MAX_SCALES) sa_cnt[tid] = 0;
+            __syncthreads();
+            {
+                int n0 = 0, n1c = 0;
+                scan([&](float d2, uint32_t) {
+                    n0 += __builtin_popcountll(__ballot(d2 < prm.radius2[0]));
+                    if (prm.n_scales > 1) n1c += __builtin_popcountll(__ballot(d2 < prm.radius2[1]));
+                });
+                if (lane == 0) { atomicAdd(&sa_cnt[0], n0); atomicAdd(&sa_cnt[1], n1c); }
+#pragma unroll
+                for (int chn = 0; chn < NCH; ++chn) gm[chn] = ghit[chn];      // later passes: only the groups that hold a hit
+            }
+            __syncthreads();
+            int tot[SA_MAX_SCALES] = {sa_cnt[0], sa_cnt[1]};
+            // 2. thresholds
+            uint32_t thr[SA_MAX_SCALES] = {0xFFFFu, 0xFFFFu};
+#pragma unroll 1
+            for (int s = 0; s < prm.n_scales; ++s) {
+                if (tot[s] <= prm.nsample[s]) continue;                       // the same in every wave
+                uint32_t prefix = 0;                     // high byte of T once known
+                int need = prm.nsample[s];               // rank of T among the hits still in play (1-based)
+#pragma unroll 1
+                for (int level = 0; level < 2; ++level) {
+                    shist[tid] = 0u;                                          // 256 threads, 256 bins
+                    __syncthreads();
+                    const float r2 = prm.radius2[s];
+                    scan([&](float d2, uint32_t k) {
+                        const bool in = d2 < r2 && (level == 0 || (k >> 8) == prefix);
+                        if (in) atomicAdd(&shist[level == 0 ? (k >> 8) : (k & 255u)], 1u);
+                    });
+                    __syncthreads();
+                    // every wave alike: lane l owns bins 4 l .. 4 l + 3; exclusive prefix over the lanes, then inside the lane
+                    uint32_t cb[4], mine = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { cb[u] = shist[4 * lane + u]; mine += cb[u]; }
+                    uint32_t incl = mine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t up = __shfl_up(incl, off);
+                        if (lane >= off) incl += up;
+                    }
+                    const uint32_t excl = incl - mine;
+                    const int wl = __builtin_ctzll(__ballot(excl < (uint32_t)need && (uint32_t)need <= incl));
+                    uint32_t run = excl, bin = 0, before = 0;
+                    bool found = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (!found && run + cb[u] >= (uint32_t)need) { bin = 4 * lane + u; before = run; found = true; }
+                        run += cb[u];
+                    }
+                    const uint32_t wbin = (uint32_t)__builtin_amdgcn_readlane((int)bin, wl);
+                    need -= (int)__builtin_amdgcn_readlane((int)before, wl);
+                    if (level == 0) prefix = wbin; else thr[s] = (prefix << 8) | wbin;
+                    __syncthreads();                                          // every wave has read the bins
+                }
+                tot[s] = prm.nsample[s];
+            }
+            // 3. this wave's share of the hits, slot 0
+            for (int i = lane; i < SA_MAX_SCALES * SA_CPW * SA_OUT; i += 64) (&sa_acc[wave][0][0][0])[i] = 0u;
+            if (lane < 4) sa_cxyz[wave][0][lane] = sa_c16[pc][lane];
+            scan([&](float d2, uint32_t k) {
+#pragma unroll
+                for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                    if (s >= prm.n_scales) break;
+                    const bool hit = d2 < prm.radius2[s] && k <= thr[s];
+                    const uint64_t mask = __ballot(hit);
+                    if (mask != 0) {
+                        if (qn[s] + 64 > SA_RING) drain_all(false);               // leaves < 64 entries in each ring
+                        const int pre = (int)dclr_lanemask_lt_popc(mask);
+                        if (hit) sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] = k;      // slot 0
+                        qn[s] += __builtin_popcountll(mask);
+                    }
+                }
+            });
+            drain_all(true);
+            __syncthreads();
+            // 4. the row
+            if (wave == 0) {
+                float *orow = out_rows + (bi * prm.npoint + jw0 + pc) * DCLR_F_STRIDE;
+                uint32_t v = 0u;
+                if ((lane >> 5) < prm.n_scales) {
+#pragma unroll
+                    for (int w = 0; w < SA_WAVES; ++w) v = dclr_umax(v, sa_acc[w][lane >> 5][0][lane & 31]);
+                }
+                orow[lane] = __uint_as_float(v);
+                if (lane < 4) orow[64 + lane] = lane < 3 ? sa_c16[pc][lane] : 0.f;
+                if (counts && lane < prm.n_scales)
+                    counts[(bi * prm.npoint + jw0 + pc) * prm.n_scales + lane] = lane == 0 ? tot[0] : tot[1];
+            }
+            __syncthreads();                                                  // slot 0 and the counters are free again
         }
     }
 
