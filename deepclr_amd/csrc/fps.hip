@@ -1408,6 +1408,14 @@ __device__ __forceinline__ void fps_accept_samples(int par, int r, int m, bool l
 // group (registers) and which slot holds it (2 bits per group). A round then reads and writes ~10 % of
 // the cloud instead of all of it (fps_stream_kernel: 1 MB per round through one CU's memory path).
 // ------------------------------------------------------------------------------------------------
+// Kernel B: the global group (256 consecutive sorted positions) that is wave w's g-th: neighbours in sorted order go to
+// different waves. (Rotating the assignment from one coarse sorting cell to the next -- 16 g + (w - g) mod 16 -- moved the
+// per-cloud imbalance to other waves and changed nothing: 1471 vs 1456 us per 16 clouds.)
+__device__ __forceinline__ int fps_paged_group(int g, int wave) { return g * 16 + wave; }
+
+#ifdef FPS_DEBUG
+__device__ unsigned long long fps_dbg2[16][8];     // cloud 0, per wave: cycles in box tests, visits, selection, wait-A, leader+B; visits; batches; rounds
+#endif
 template <int NG, int MODE>                       // MODE as in fps_pruned_kernel: 0 one sample per barrier round, 1 several
 __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int m, const float *__restrict__ pts,
                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
@@ -1506,9 +1514,25 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     gvec gbest;                                            // per lane: largest running minimum of the 4 slots
     gvec gsec;                                             // MODE 1: the largest among the lane's other 3 slots
     uint32_t gslot = 0;                                    // 2 bits per group: the slot holding it
+    // MODE 1 keeps the running minima on the CU: slots 0..2 of every group in registers (element g of a 16-vector,
+    // indexed dynamically: register-relative moves), slot 3 in LDS (64 KB) -- 64 registers of minima beside a round's
+    // working set do not fit 128. The workspace copy, its read and write-back per visited group (a third of the
+    // kernel's HBM traffic) are gone; the workspace holds only the read-only sorted coordinates.
+    constexpr bool REGTD = MODE == 1;
+    typedef float fps_v16 __attribute__((ext_vector_type(16)));
+    fps_v16 tdr[3];
+    __shared__ float tdl3[REGTD ? 16 : 1][REGTD ? WGS : 1];
+#define FPS_TD_GET(i_, g_) ((i_) == 0 ? tdr[0][g_] : (i_) == 1 ? tdr[1][g_] : (i_) == 2 ? tdr[2][g_] : tdl3[REGTD ? (g_) : 0][REGTD ? t : 0])
+#define FPS_TD_SET(i_, g_, v_)                                                       \
+    {                                                                               \
+        if ((i_) == 0) tdr[0][g_] = (v_);                                           \
+        else if ((i_) == 1) tdr[1][g_] = (v_);                                      \
+        else if ((i_) == 2) tdr[2][g_] = (v_);                                      \
+        else tdl3[REGTD ? (g_) : 0][REGTD ? t : 0] = (v_);                          \
+    }
 #pragma unroll 1
     for (int g = 0; g < NG; ++g) {
-        const int base = (g * NW + wave) * 256 + lane;
+        const int base = fps_paged_group(g, wave) * 256 + lane;
         uint32_t tk[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1549,7 +1573,8 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 any = true;
             }
             spts[base + 64 * i] = make_float4(x, y, z, __uint_as_float(k));
-            std_[base + 64 * i] = d;
+            if constexpr (REGTD) FPS_TD_SET(i, g, d)
+            else std_[base + 64 * i] = d;
         }
         float box[6];
 #pragma unroll
@@ -1559,7 +1584,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             box[a] = l; box[3 + a] = h;
         }
         if (group_box && lane < 8)
-            group_box[(size_t)(g * NW + wave) * 8 + lane] =
+            group_box[(size_t)fps_paged_group(g, wave) * 8 + lane] =
                 lane == 0 ? box[0] : lane == 1 ? box[1] : lane == 2 ? box[2] : lane == 3 ? box[3]
                 : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         vec_set<NG>(gbest, g, any ? 0.f : -1.0f);
@@ -1577,7 +1602,13 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         //      the points are in registers the wave reduces the group's best point, its tie key and its second-best
         //      value into lane g. Selecting the wave's candidate and runner-up is then a 16-lane reduction over
         //      registers, with no fetch of the winner. gmaxv is the group's exact largest running minimum here. -------
-        constexpr int J = 3, B = 2;
+#ifndef FPS_PAGED_J
+#define FPS_PAGED_J 3
+#endif
+#ifndef FPS_PAGED_B
+#define FPS_PAGED_B 1          // groups in flight per wave: 2 would need 24 bytes of scratch beside the register-resident minima
+#endif
+        constexpr int J = FPS_PAGED_J, B = FPS_PAGED_B;
         if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
         __syncthreads();
         float pcx[J] = {pts[0]}, pcy[J] = {pts[1]}, pcz[J] = {pts[2]};
@@ -1586,17 +1617,32 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         uint32_t gsv = 0u, gkey = 0xFFFFFFFFu;                 // lane g: second-best value bits, tie key of the best point
         float gx = 0.f, gy = 0.f, gz = 0.f;                    // lane g: the best point of group g
         int32_t gk = 0;
+        uint32_t gstate = 0u;                                  // lane g: (lane << 3 | slot << 1) of the best point | entry valid
         unsigned long long c_packed = (unsigned long long)wave;
         uint32_t c_ru = 0u;
         int sr = 0;
+#ifdef FPS_DEBUG
+        unsigned long long a_box = 0, a_vis = 0, a_sel = 0, a_w1 = 0, a_lead = 0, a_batches = 0, a_touch = 0;
+#endif
         for (int r = 1; r < m;) {
-            uint32_t act = 0;
+#ifdef FPS_DEBUG
+            unsigned long long q0, q1, q2, q3, q4, q5;
+            FPS_STAMP(q0);
+#endif
+            uint32_t act = 0, actj[J];
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                if (j >= np) break;                                       // wave-uniform
+                actj[j] = 0u;
+                if (j >= np) continue;                                    // wave-uniform
                 const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], pcx[j], pcy[j], pcz[j]);
-                act |= (uint32_t)__ballot(lane < NG && lbv < gmaxv);
+                actj[j] = (uint32_t)__ballot(lane < NG && lbv < gmaxv);
+                act |= actj[j];
             }
+#ifdef FPS_DEBUG
+            FPS_STAMP(q1);
+            q2 = q1;
+            a_batches += (__builtin_popcount(act) + B - 1) / B; a_touch += __builtin_popcount(act);
+#endif
             if (act != 0) {                                               // wave-uniform
                 for (uint32_t rem = act; rem != 0;) {
                     int gs[B];
@@ -1612,31 +1658,46 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
 #pragma unroll
                     for (int u = 0; u < B; ++u) {
                         if (!live[u]) break;                              // wave-uniform
-                        const int base = (gs[u] * NW + wave) * 256 + lane;
+                        const int base = fps_paged_group(gs[u], wave) * 256 + lane;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { q[u][i] = spts[base + 64 * i]; o[u][i] = std_[base + 64 * i]; }
+                        for (int i = 0; i < 4; ++i) { q[u][i] = spts[base + 64 * i]; o[u][i] = FPS_TD_GET(i, gs[u]); }
                     }
 #pragma unroll
                     for (int u = 0; u < B; ++u) {
                         if (!live[u]) break;                              // wave-uniform
                         const int g = gs[u];
-                        const int base = (g * NW + wave) * 256 + lane;
 #pragma unroll
                         for (int j = 0; j < J; ++j) {
-                            if (j >= np) break;
+                            if (((actj[j] >> g) & 1u) == 0) continue;     // wave-uniform: sample j cannot change this group
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float d = dclr_sqdist(q[u][i].x, q[u][i].y, q[u][i].z, pcx[j], pcy[j], pcz[j]);
                                 asm("v_min_f32 %0, %1, %2" : "=v"(o[u][i]) : "v"(d), "v"(o[u][i]));
                             }
                         }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) FPS_TD_SET(i, g, o[u][i])
+#ifndef FPS_PAGED_NOLAZY
+                        // Did the group's best point keep its value? Running minima only decrease, so then the group's
+                        // entry (b_g, best point, key) stands; its runner-up may now be too large, which only makes the
+                        // leader's test (v > u) more cautious. 40 % of the visits end here (as in fps_pruned_kernel MODE 3).
+                        {
+                            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)gstate, g);   // lane << 3 | slot << 1 | valid
+                            const uint32_t old_b = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gmaxv), g);
+                            const int hs = (int)((st >> 1) & 3u);
+                            const float hv = hs == 0 ? o[u][0] : hs == 1 ? o[u][1] : hs == 2 ? o[u][2] : o[u][3];   // uniform selects
+                            const uint32_t now = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(hv), (int)(st >> 3));
+                            if ((st & 1u) != 0 && now == old_b) continue;                              // wave-uniform
+                        }
+#endif
                         // this lane: best slot (slots ascend in tie-key order, strict > keeps the first) and the rest
                         float best = -1.0f, sec = -1.0f;
                         float4 bq = q[u][0];
+                        int bslot = 0;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            std_[base + 64 * i] = o[u][i];
                             const bool gt = o[u][i] > best;
+                            bslot = gt ? i : bslot;
                             sec = fmaxf(sec, gt ? best : o[u][i]);
                             bq.x = gt ? q[u][i].x : bq.x; bq.y = gt ? q[u][i].y : bq.y;
                             bq.z = gt ? q[u][i].z : bq.z; bq.w = gt ? q[u][i].w : bq.w;
@@ -1661,14 +1722,19 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                         const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.y), wl));
                         const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.z), wl));
                         const int32_t wk = __builtin_amdgcn_readlane(__float_as_int(bq.w), wl);
+                        const int wslot = __builtin_amdgcn_readlane(bslot, wl);
                         if (lane == g) {
                             gmaxv = __uint_as_float(gmx);
                             gsv = g2;
                             gkey = fps_tk1024((uint32_t)wk);
                             gx = wx; gy = wy; gz = wz; gk = wk;
+                            gstate = ((uint32_t)wl << 3) | ((uint32_t)wslot << 1) | (hl != 0 ? 1u : 0u);
                         }
                     }
                 }
+#ifdef FPS_DEBUG
+                FPS_STAMP(q2);
+#endif
                 // the wave's candidate: largest group maximum, ties by key; runner-up: the other groups' maxima and the
                 // winner group's second-best
                 const bool has = lane < NG && gkey != 0xFFFFFFFFu;
@@ -1693,15 +1759,32 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 wpk[par][wave] = c_packed;
                 wru[par][wave] = c_ru;
             }
+#ifdef FPS_DEBUG
+            FPS_STAMP(q3);
+#endif
             __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(q4);
+#endif
             if (wave == 0) fps_accept_samples<J>(par, r, m, temp != nullptr, lane, wpk, wru, cand, picked, plist, &plist_n);
             __syncthreads();
+#ifdef FPS_DEBUG
+            FPS_STAMP(q5);
+            a_box += q1 - q0; a_vis += q2 - q1; a_sel += q3 - q2; a_w1 += q4 - q3; a_lead += q5 - q4;
+#endif
             np = plist_n;
 #pragma unroll
             for (int j = 0; j < J; ++j) { pcx[j] = plist[j][0]; pcy[j] = plist[j][1]; pcz[j] = plist[j][2]; }
             r += np;
             sr += 1;
         }
+#ifdef FPS_DEBUG
+        if (blockIdx.x == 0 && lane == 0) {
+            fps_dbg2[wave][0] = a_box; fps_dbg2[wave][1] = a_vis; fps_dbg2[wave][2] = a_sel; fps_dbg2[wave][3] = a_w1;
+            fps_dbg2[wave][4] = a_lead; fps_dbg2[wave][5] = a_touch; fps_dbg2[wave][6] = a_batches;
+            fps_dbg2[wave][7] = (unsigned long long)sr;
+        }
+#endif
         if (group_box && t == 0) group_box[6] = (float)sr;                // diagnostics: barrier rounds this cloud took
     } else {
     float cx = pts[0], cy = pts[1], cz = pts[2];
@@ -1717,7 +1800,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         if (act != 0) {                                           // wave-uniform
             for (uint32_t rem = act; rem != 0; rem &= rem - 1) {
                 const int g = __builtin_ctz(rem);
-                const int base = (g * NW + wave) * 256 + lane;
+                const int base = fps_paged_group(g, wave) * 256 + lane;
                 float4 q[4];
                 float o[4];
 #pragma unroll
@@ -1757,7 +1840,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                 hg = eq ? g : hg;
             }
             // fetch the candidate point (position, original index) while the wave reduction runs
-            const float4 mine4 = spts[(hg * NW + wave) * 256 + 64 * (int)((gslot >> (2 * hg)) & 3u) + lane];
+            const float4 mine4 = spts[fps_paged_group(hg, wave) * 256 + 64 * (int)((gslot >> (2 * hg)) & 3u) + lane];
             const uint32_t wmax = dclr_wave_max_u32(lbest < 0.f ? 0u : __float_as_uint(lbest));
             const float wmaxf = __uint_as_float(wmax);
             const bool holder = lbest == wmaxf;
@@ -1777,7 +1860,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                     float4 c4 = mine4;
                     uint32_t kg = 0xFFFFFFFFu;
                     if (vec_get<NG>(gbest, g) == wmaxf) {
-                        c4 = spts[(g * NW + wave) * 256 + 64 * (int)((gslot >> (2 * g)) & 3u) + lane];
+                        c4 = spts[fps_paged_group(g, wave) * 256 + 64 * (int)((gslot >> (2 * g)) & 3u) + lane];
                         kg = fps_tk1024(__float_as_uint(c4.w));
                     }
                     const bool take = kg < key;
@@ -1821,490 +1904,18 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     if (temp) {                                                // level-1 contract: the running minima go back to temp
 #pragma unroll 1
         for (int g = 0; g < NG; ++g) {
-            const int base = (g * NW + wave) * 256 + lane;
+            const int base = fps_paged_group(g, wave) * 256 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t k = __float_as_uint(spts[base + 64 * i].w);
-                if (k != 0xFFFFFFFFu) temp[k] = std_[base + 64 * i];
+                if (k != 0xFFFFFFFFu) temp[k] = REGTD ? FPS_TD_GET(i, g) : std_[base + 64 * i];
             }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Kernel B2 (default for 16384 < n <= 65536): the running minima stay in REGISTERS, only the read-only sorted
-// coordinates live in the workspace, and pruning works on sub-groups of 64 points.
-//   * 1024 * P padded points in sorted order; sub-group s = sorted positions [64 s, 64 s + 64), one point per lane.
-//     Wave w owns sub-groups w, 16 + w, 32 + w, ... (local g = s >> 4: spatial neighbours on different waves), so a
-//     lane holds NGW = 4 P running minima (64 registers at 65536 points) -- the workspace copy of them, its read and
-//     its write-back per touched group (a third of kernel B's 8.4 GB per 160-cloud launch) are gone;
-//   * lane g of a wave keeps sub-group g's box, its exact largest running minimum b_g, the runner-up u_g, and the
-//     best point itself (tie key, index, coordinates). A touched sub-group costs ONE 16-byte load per lane (1 KB per
-//     wave against 4 KB + 2 x 1 KB for kernel B's 256-point groups), up to FPS_P2_B of them in flight together, and
-//     the finer boxes touch a third of the points per sample;
-//   * samples per barrier round, acceptance and tie rules: exactly fps_pruned_kernel MODE 1 (per-wave candidate +
-//     runner-up, leader = fps_accept_samples); all accepted samples are applied to every touched sub-group (a sample
-//     whose box bound spares a sub-group cannot change it: min is idempotent there).
-// Exported groups (set abstraction): group G = sub-groups 4 G .. 4 G + 3 = sorted positions [256 G, 256 G + 256), its
-// box the union of their boxes -- the same point sets as kernel B's groups.
-// ------------------------------------------------------------------------------------------------
-#ifndef FPS_P2_B
-#define FPS_P2_B 2
-#endif
-#ifndef FPS_P2_SETUP
-#define FPS_P2_SETUP 4
-#endif
-#define FPS_C4(b, X) X((b)) X((b) + 1) X((b) + 2) X((b) + 3)
-#define FPS_C16(b, X) FPS_C4((b), X) FPS_C4((b) + 4, X) FPS_C4((b) + 8, X) FPS_C4((b) + 12, X)
-#define FPS_C64(X) FPS_C16(0, X) FPS_C16(16, X) FPS_C16(32, X) FPS_C16(48, X)
-
-#ifdef FPS_DEBUG
-__device__ unsigned long long fps_dbg2[16][8];     // cloud 0, per wave: cycles in box tests, visits, selection, wait-A, leader+B; visits; batches; rounds
-#endif
-template <int NGW>                                 // sub-groups per wave: 32 (n <= 32768) or 64
-__global__ __launch_bounds__(1024) void fps_paged2_kernel(int n, int pstride, int m, const float *__restrict__ pts,
-                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
-                                                          uint32_t *__restrict__ sidx_all, uint16_t *__restrict__ cell_all,
-                                                          float *__restrict__ group_box, float *__restrict__ temp) {
-    constexpr int WGS = 1024, NW = 16, NP = WGS * NGW, NS = NW * NGW, BINS = 4096, J = 3, B = FPS_P2_B;
-    static_assert(NGW == 32 || NGW == 64, "one sub-group per lane of the owning wave");
-    __shared__ FpsCand cand[2][16];
-    __shared__ unsigned long long wpk[2][16];              // per-wave packed candidate, by round parity
-    __shared__ uint32_t wru[2][16];                        // per-wave runner-up value
-    __shared__ int plist_n;                                // samples accepted for the next round
-    __shared__ float red[6][16];
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t hist[BINS];
-    __shared__ float sbox[NS][6];                          // sub-group boxes (export: unions of four)
-    extern __shared__ int32_t picked[];
-
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    pts += (size_t)blockIdx.x * n * pstride;
-    idx += (size_t)blockIdx.x * m;
-    float4 *spts = spts_all + (size_t)blockIdx.x * NP;
-    uint32_t *sidx = sidx_all + (size_t)blockIdx.x * NP;
-    uint16_t *cellof = cell_all + (size_t)blockIdx.x * NP;
-    if (group_box) group_box += (size_t)blockIdx.x * (NS / 4) * 8;
-    if (temp) temp += (size_t)blockIdx.x * n;
-
-    // ---- 1. bounding box ------------------------------------------------------------------------
-    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int k = t; k < n; k += WGS)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float v = pts[(size_t)k * pstride + a];
-            lo[a] = fminf(lo[a], v);
-            hi[a] = fmaxf(hi[a], v);
-        }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float l = fps_shfl_min(lo[a]), h = fps_shfl_max(hi[a]);
-        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
-    }
-    for (int u = t; u < BINS; u += WGS) hist[u] = 0u;
-    if (t < 32) { cand[t >> 4][t & 15] = FpsCand{0, 0.f, 0.f, 0.f}; wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
-    __syncthreads();
-    float ext[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float l = red[a][0], h = red[3 + a][0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
-        lo[a] = l;
-        ext[a] = h - l;
-    }
-    // ---- 2. counting sort by a 12-bit cell, bits dealt to the axes by extent (any order yields the same samples) ----
-    const FpsGrid grid = fps_make_grid(ext);
-    for (int k = t; k < n; k += WGS) {
-        const float *pk = pts + (size_t)k * pstride;
-        const uint32_t mc = fps_cell(grid, pk[0] - lo[0], pk[1] - lo[1], pk[2] - lo[2]);
-        atomicAdd(&hist[mc], 1u);
-        cellof[k] = (uint16_t)mc;
-    }
-    __syncthreads();
-    {
-        constexpr int BPT = BINS / WGS;
-        uint32_t c[BPT], mine = 0;
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) { c[u] = hist[BPT * t + u]; mine += c[u]; }
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - mine;
-        for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) { hist[BPT * t + u] = run; run += c[u]; }
-    }
-    __syncthreads();
-    for (int k = t; k < n; k += WGS) sidx[atomicAdd(&hist[cellof[k]], 1u)] = (uint32_t)k;   // own cellof entries
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-    // ---- 3. sub-groups: this wave's g-th = sorted positions [64 (16 g + wave), + 64), one point per lane ------------
-    // running minima: element g of the lane = its point of sub-group g. g is wave-uniform and only known at run time:
-    // 16-element vectors indexed dynamically become register-relative moves (s_set_gpr_idx), a switch picks the vector.
-    // At 65536 points the last 16 sub-groups of every wave keep theirs in LDS (64 KB) instead: 64 registers of minima
-    // beside the working set of a round did not fit 128 registers without spilling a whole vector.
-    typedef float fps_v16 __attribute__((ext_vector_type(16)));
-    constexpr int NREG = NGW > 48 ? 48 : NGW, NLDS = NGW - NREG;
-    fps_v16 td[NREG / 16];
-    __shared__ float tdl[NLDS > 0 ? NLDS : 1][NLDS > 0 ? WGS : 1];
-#define FPS_TD_GET(g_, v_)                                                          \
-    {                                                                               \
-        const int TD_E = (g_) & 15;                                                 \
-        switch ((g_) >> 4) {                                                        \
-            case 0: v_ = td[0][TD_E]; break;                                        \
-            case 1: v_ = td[1][TD_E]; break;                                        \
-            case 2: v_ = td[NREG > 32 ? 2 : 0][TD_E]; break;                        \
-            default: v_ = tdl[NLDS > 0 ? TD_E : 0][NLDS > 0 ? t : 0]; break;       \
-        }                                                                           \
-    }
-#define FPS_TD_SET(g_, v_)                                                          \
-    {                                                                               \
-        const int TD_E = (g_) & 15;                                                 \
-        switch ((g_) >> 4) {                                                        \
-            case 0: td[0][TD_E] = v_; break;                                        \
-            case 1: td[1][TD_E] = v_; break;                                        \
-            case 2: if (NREG > 32) td[NREG > 32 ? 2 : 0][TD_E] = v_; break;         \
-            default: if (NLDS > 0) tdl[NLDS > 0 ? TD_E : 0][NLDS > 0 ? t : 0] = v_; break; \
-        }                                                                           \
-    }
-    // lane g's box of sub-group g is sbox[16 g + wave] (LDS, read once per round: six registers fewer beside the minima)
-    float gmaxv = 0.f;                                     // lane g: b_g, exact (+inf before the first update; 0: empty)
-    // (four sub-groups per step: their index and coordinate fetches are two batched round trips, not eight dependent ones)
-#pragma unroll 1
-    for (int g0 = 0; g0 < NGW; g0 += FPS_P2_SETUP) {
-        uint32_t kk[FPS_P2_SETUP];
-#pragma unroll
-        for (int u = 0; u < FPS_P2_SETUP; ++u) {
-            const int pos = ((g0 + u) * NW + wave) * 64 + lane;
-            kk[u] = pos < n ? sidx[pos] : 0xFFFFFFFFu;
-        }
-        float xs[FPS_P2_SETUP], ys[FPS_P2_SETUP], zs[FPS_P2_SETUP], ds[FPS_P2_SETUP];
-#pragma unroll
-        for (int u = 0; u < FPS_P2_SETUP; ++u) {
-            // padding: far away (set abstraction reads these groups too: never inside a ball) and running minimum -2,
-            // which no update raises and which counts as 0 in every maximum
-            xs[u] = ys[u] = zs[u] = 3.0e38f; ds[u] = -2.0f;
-            if (kk[u] != 0xFFFFFFFFu) {
-                const float *pk = pts + (size_t)kk[u] * pstride;
-                xs[u] = pk[0]; ys[u] = pk[1]; zs[u] = pk[2];
-                ds[u] = temp ? temp[kk[u]] : 1e10f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < FPS_P2_SETUP; ++u) {
-            const int g = g0 + u, s = g * NW + wave, pos = s * 64 + lane;
-            const bool real = kk[u] != 0xFFFFFFFFu;
-            spts[pos] = make_float4(xs[u], ys[u], zs[u], __uint_as_float(kk[u]));
-            FPS_TD_SET(g, ds[u])
-            const float bl[3] = {xs[u], ys[u], zs[u]};                               // padding: +3e38
-            const float bh[3] = {real ? xs[u] : -3.0e38f, real ? ys[u] : -3.0e38f, real ? zs[u] : -3.0e38f};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float l = fps_shfl_min(bl[a]), h = fps_shfl_max(bh[a]);
-                if (lane == 0) { sbox[s][a] = l; sbox[s][3 + a] = h; }
-            }
-            const bool group_any = __ballot(real) != 0;                              // all lanes vote
-            if (lane == g && group_any) gmaxv = __uint_as_float(0x7F800000u);        // +inf forces the first update
-        }
-    }
-    __syncthreads();
-    if (group_box && t < NS / 4) {
-        float b6[6];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            b6[a] = fminf(fminf(sbox[4 * t][a], sbox[4 * t + 1][a]), fminf(sbox[4 * t + 2][a], sbox[4 * t + 3][a]));
-            b6[3 + a] = fmaxf(fmaxf(sbox[4 * t][3 + a], sbox[4 * t + 1][3 + a]), fmaxf(sbox[4 * t + 2][3 + a], sbox[4 * t + 3][3 + a]));
-        }
-        float4 *dst = reinterpret_cast<float4 *>(group_box + (size_t)t * 8);
-        dst[0] = make_float4(b6[0], b6[1], b6[2], b6[3]);
-        dst[1] = make_float4(b6[4], b6[5], 0.f, 0.f);
-    }
-    // every thread re-reads only the spts entries it wrote itself (same positions): no further fence needed
-
-    // ---- 4. sampling rounds ---------------------------------------------------------------------------------------------
-    // A round has three barriers:
-    //   visits    every wave updates the sub-groups its masks name (first batch already loaded), then publishes its
-    //             candidate and runner-up                                                               -> barrier A
-    //   order     wave 0 extracts the J best published candidates in value order (ties by key) into clist  -> barrier A2
-    //   tests     EVERY wave tests the J candidates against the boxes of its 64 sub-groups (one mask per candidate) and
-    //             requests the first visits of candidate 0, which is certain to be accepted -- while wave 0 runs the
-    //             pairwise acceptance tests (fps_pruned_kernel MODE 1: v_j > u_i and sqdist(c_j, c_i) >= v_j for every
-    //             earlier i) and publishes the count                                                     -> barrier B
-    // The box tests (16 waves x ~70 instructions on 4 SIMDs) and the first loads' latency used to sit in front of the
-    // visits; here they run beside the leader, when 15 waves had nothing to do. A sample is applied only to the
-    // sub-groups its own mask names.
-    __shared__ float4 clist[J];                            // candidate j: x, y, z, -
-    __shared__ uint32_t cmeta[J][4];                       // wave 0 only reads these back: value, runner-up of its wave, index
-    float pcx[J] = {pts[0]}, pcy[J] = {pts[1]}, pcz[J] = {pts[2]};      // wave-uniform (scalar registers)
-    unsigned long long mk[J];                              // mk[j]: the sub-groups of this wave sample j can change
-    int np = 1;
-    if (t == 0) picked[0] = 0;
-    uint32_t gsv = 0u, gkey = 0xFFFFFFFFu;                 // lane g: u_g (bits), tie key of the best point (~0: none yet / empty)
-    float gx = 0.f, gy = 0.f, gz = 0.f;                    // lane g: the best point of sub-group g
-    int32_t gk = 0;
-    uint32_t gstate = 0u;                                  // lane g: (lane holding the best point) << 1 | entry valid
-    unsigned long long c_packed = (unsigned long long)wave;
-    uint32_t c_ru = 0u;
-    int sr = 0, n_touch = 0, n_lazy = 0;
-    // sample 0 = point 0 reaches every non-empty sub-group (b_g = +inf)
-    mk[0] = __ballot(lane < NGW && gmaxv > 0.f);
-#pragma unroll
-    for (int j = 1; j < J; ++j) mk[j] = 0ull;
-    int gs[B];
-    bool live[B];
-    float4 q[B];
-    unsigned long long pre = 0ull;                         // the sub-groups whose points are already requested
-    auto request = [&](unsigned long long &from) {         // take up to B sub-groups out of `from` and request their points
-#pragma unroll
-        for (int u = 0; u < B; ++u) {
-            live[u] = from != 0;
-            gs[u] = live[u] ? __builtin_ctzll(from) : 0;
-            if (live[u]) from &= from - 1;
-            // scalar base + 32-bit lane offset (no 64-bit address registers beside the minima)
-            if (live[u])
-                q[u] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spts) +
-                                                         (((uint32_t)(gs[u] * NW + wave) << 10) | ((uint32_t)lane << 4)));
-        }
-    };
-    {
-        unsigned long long from = mk[0];
-        request(from);
-        pre = mk[0] & ~from;
-    }
-#ifdef FPS_DEBUG
-    unsigned long long a_box = 0, a_vis = 0, a_sel = 0, a_w1 = 0, a_lead = 0, a_batches = 0;
-#endif
-    for (int r = 1; r < m;) {
-#ifdef FPS_DEBUG
-        unsigned long long q0, q1, q2, q3, q4, q5;
-        FPS_STAMP(q0);
-#endif
-        unsigned long long act = mk[0];
-#pragma unroll
-        for (int j = 1; j < J; ++j) act |= j < np ? mk[j] : 0ull;
-#ifdef FPS_DEBUG
-        FPS_STAMP(q1);
-        q2 = q1;
-        a_batches += (__builtin_popcountll(act) + B - 1) / B;
-#endif
-        if (act != 0) {                                                   // wave-uniform
-            n_touch += __builtin_popcountll(act);
-            unsigned long long rem = act & ~pre;
-            for (bool first = true;; first = false) {
-                if (!first) request(rem);                                 // the first batch was requested beside the leader
-#pragma unroll
-                for (int u = 0; u < B; ++u) {
-                    if (!live[u]) break;                                  // wave-uniform
-                    const int g = gs[u];
-                    float d;
-                    FPS_TD_GET(g, d)
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        if (j >= np) break;
-                        if (((mk[j] >> g) & 1ull) == 0) continue;         // wave-uniform: sample j cannot change this sub-group
-                        const float dj = dclr_sqdist(q[u].x, q[u].y, q[u].z, pcx[j], pcy[j], pcz[j]);
-                        asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(dj), "v"(d));
-                    }
-                    FPS_TD_SET(g, d)
-                    const uint32_t bbits = d < 0.f ? 0u : __float_as_uint(d);
-#ifndef FPS_P2_NOLAZY
-                    // Did the sub-group's best point keep its value? Running minima only decrease, so then b_g and the
-                    // best point stand; u_g may now be too large, which only makes the leader's test (v > u) more
-                    // cautious. Most visits nibble at a sub-group's fringe and end here (as in fps_pruned_kernel MODE 3).
-                    {
-                        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)gstate, g);      // holder lane << 1 | valid
-                        const uint32_t old_b = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(gmaxv), g);
-                        const uint32_t now = (uint32_t)__builtin_amdgcn_readlane((int)bbits, (int)(st >> 1));
-                        if ((st & 1u) != 0 && now == old_b) { n_lazy += 1; continue; }                 // wave-uniform
-                    }
-#endif
-                    // the sub-group: largest value and runner-up in one top-2 reduction, then its holder (ties by key)
-                    uint32_t m1 = bbits, m2 = 0u;
-#define FPS_TOP2_STEP(CTRL, RM)                                                                     \
-                    {                                                                               \
-                        const uint32_t o1 = dclr_dpp<CTRL, RM>(0u, m1), o2 = dclr_dpp<CTRL, RM>(0u, m2); \
-                        const uint32_t lo2 = dclr_umin(m1, o1);                                     \
-                        m1 = dclr_umax(m1, o1);                                                     \
-                        m2 = dclr_umax(dclr_umax(m2, o2), lo2);                                     \
-                    }
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(1), 0xf)
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(2), 0xf)
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(4), 0xf)
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_SHR(8), 0xf)
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_BCAST15, 0xa)
-                    FPS_TOP2_STEP(DCLR_DPP_ROW_BCAST31, 0xc)
-#undef FPS_TOP2_STEP
-                    const uint32_t gm1 = (uint32_t)__builtin_amdgcn_readlane((int)m1, 63);
-                    const uint32_t gm2 = (uint32_t)__builtin_amdgcn_readlane((int)m2, 63);
-                    const bool holder = d >= 0.f && bbits == gm1;
-                    const uint64_t hl = __ballot(holder);
-                    int wl;
-                    if ((hl & (hl - 1)) == 0) {
-                        wl = hl != 0 ? __builtin_ctzll(hl) : 0;
-                    } else {
-                        const uint32_t key = holder ? fps_tk1024(__float_as_uint(q[u].w)) : 0xFFFFFFFFu;
-                        const uint32_t kmin = dclr_wave_min_u32(key);
-                        wl = __builtin_ctzll(__ballot(key == kmin));
-                    }
-                    const float wx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q[u].x), wl));
-                    const float wy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q[u].y), wl));
-                    const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q[u].z), wl));
-                    const int32_t wk = __builtin_amdgcn_readlane(__float_as_int(q[u].w), wl);
-                    if (lane == g) {
-                        gmaxv = __uint_as_float(gm1);
-                        gsv = gm2;
-                        gkey = hl != 0 ? fps_tk1024((uint32_t)wk) : 0xFFFFFFFFu;
-                        gx = wx; gy = wy; gz = wz; gk = wk;
-                        gstate = ((uint32_t)wl << 1) | (hl != 0 ? 1u : 0u);
-                    }
-                }
-                if (rem == 0) break;
-            }
-#ifdef FPS_DEBUG
-            FPS_STAMP(q2);
-#endif
-            // the wave's candidate: largest sub-group maximum, ties by key; runner-up: the other sub-groups' maxima and
-            // the winner's second-best
-            const bool has = lane < NGW && gkey != 0xFFFFFFFFu;
-            const uint32_t vbits = has ? __float_as_uint(gmaxv) : 0u;
-            const uint32_t wmax = dclr_wave_max_u32(vbits);
-            const bool hold = has && vbits == wmax;
-            const uint64_t hw = __ballot(hold);
-            uint32_t kmin;
-            int wgp;
-            if ((hw & (hw - 1)) == 0) {
-                wgp = hw != 0 ? __builtin_ctzll(hw) : 0;
-                kmin = (uint32_t)__builtin_amdgcn_readlane((int)gkey, wgp);
-            } else {
-                kmin = dclr_wave_min_u32(hold ? gkey : 0xFFFFFFFFu);
-                wgp = __builtin_ctzll(__ballot(hold && gkey == kmin));
-            }
-            if (hw != 0) {
-                c_packed = ((unsigned long long)wmax << 32) | ((unsigned long long)(0xFFFFu - kmin) << 16) |
-                           (unsigned long long)wave;
-                // both parities: wave 0 finished reading the other parity's entries before barrier A2 of the previous round
-                if (lane == wgp) {
-                    const FpsCand c{gk, gx, gy, gz};
-                    cand[0][wave] = c;
-                    cand[1][wave] = c;
-                }
-                c_ru = dclr_wave_max_u32(has ? (lane == wgp ? gsv : vbits) : 0u);
-            }
-        }
-        const int par = sr & 1;
-        if (lane == 0) {
-            wpk[par][wave] = c_packed;
-            wru[par][wave] = c_ru;
-        }
-#ifdef FPS_DEBUG
-        FPS_STAMP(q3);
-#endif
-        __syncthreads();                                                  // ---- barrier A
-#ifdef FPS_DEBUG
-        FPS_STAMP(q4);
-#endif
-        if (wave == 0) {
-            // the J best candidates in value order, ties by key (the order fps_accept_samples takes them in)
-            const unsigned long long e = wpk[par][lane & 15];
-            const uint32_t e_ru = wru[par][lane & 15];
-            const FpsCand w = cand[par][lane & 15];
-            uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const uint32_t m_hi = dclr_row16_max_u32(e_hi);
-                const uint32_t holders = (uint32_t)__ballot(e_hi == m_hi) & 0xFFFFu;
-                int wid;
-                if ((holders & (holders - 1)) == 0) wid = __builtin_ctz(holders);
-                else wid = (int)(dclr_row16_max_u32(e_hi == m_hi ? e_lo : 0u) & 15u);
-                if (lane == wid) {
-                    clist[j] = make_float4(w.x, w.y, w.z, 0.f);
-                    cmeta[j][0] = m_hi; cmeta[j][1] = e_ru; cmeta[j][2] = (uint32_t)w.k;
-                }
-                const bool mine = (lane & 15) == wid;
-                e_hi = mine ? 0u : e_hi;
-                e_lo = mine ? 0u : e_lo;
-            }
-        }
-        __syncthreads();                                                  // ---- barrier A2
-        {
-            auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
-            const float2 *bx = reinterpret_cast<const float2 *>(&sbox[(lane < NGW ? lane : 0) * NW + wave][0]);
-            const float2 b01 = bx[0], b23 = bx[1], b45 = bx[2];           // min x y | min z, max x | max y z
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const float4 cj = clist[j];
-                pcx[j] = uni(cj.x); pcy[j] = uni(cj.y); pcz[j] = uni(cj.z);
-                const float lbv = fps_box_lower_bound(b01.x, b01.y, b23.x, b23.y, b45.x, b45.y, pcx[j], pcy[j], pcz[j]);
-                mk[j] = __ballot(lane < NGW && lbv < gmaxv);
-            }
-            unsigned long long from = mk[0];
-            request(from);
-            pre = mk[0] & ~from;
-        }
-        if (wave == 0) {
-            // acceptance: candidate j joins iff every earlier one did and it passes the test against each of them; the
-            // level-1 contract (temp = minima over the first m - 1 samples) gives the final sample a round of its own
-            uint32_t v[J], ru[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) { v[j] = cmeta[j][0]; ru[j] = cmeta[j][1]; }
-            int cnt = 1;
-            bool open = true;
-#pragma unroll
-            for (int j = 1; j < J; ++j) {
-                bool ok = r + j < m && !(temp != nullptr && r + j == m - 1);
-#pragma unroll
-                for (int i = 0; i < j; ++i) {
-                    const uint32_t dist = __float_as_uint(dclr_sqdist(pcx[j], pcy[j], pcz[j], pcx[i], pcy[i], pcz[i]));
-                    ok = ok && v[j] > ru[i] && dist >= v[j];
-                }
-                open = open && ok;
-                cnt += open ? 1 : 0;
-            }
-            if (lane < J && lane < cnt) picked[r + lane] = (int32_t)cmeta[lane][2];
-            if (lane == 0) plist_n = cnt;
-        }
-        __syncthreads();                                                  // ---- barrier B
-#ifdef FPS_DEBUG
-        FPS_STAMP(q5);
-        a_box += q1 - q0; a_vis += q2 - q1; a_sel += q3 - q2; a_w1 += q4 - q3; a_lead += q5 - q4;
-#endif
-        np = __builtin_amdgcn_readfirstlane(plist_n);
-        r += np;
-        sr += 1;
-    }
-#ifdef FPS_DEBUG
-    if (blockIdx.x == 0 && lane == 0) {
-        fps_dbg2[wave][0] = a_box; fps_dbg2[wave][1] = a_vis; fps_dbg2[wave][2] = a_sel; fps_dbg2[wave][3] = a_w1;
-        fps_dbg2[wave][4] = a_lead; fps_dbg2[wave][5] = (unsigned long long)n_touch; fps_dbg2[wave][6] = a_batches;
-        fps_dbg2[wave][7] = (unsigned long long)sr;
-    }
-#endif
-    if (group_box && t == 0) group_box[6] = (float)sr;                    // diagnostics: barrier rounds this cloud took
-    if (group_box && lane == 0) atomicAdd(&group_box[7], (float)n_touch); //              and sub-group visits (64 points each)
-    if (group_box && lane == 0) atomicAdd(&group_box[8 + 7], (float)n_lazy);  //           ... of which left the entry alone
-    __syncthreads();
-    for (int i = t; i < m; i += WGS) idx[i] = picked[i];
-    if (temp) {                                                           // level-1 contract: the running minima go back to temp
-#pragma unroll 1
-        for (int g = 0; g < NGW; ++g) {
-            const int pos = (g * NW + wave) * 64 + lane;
-            float d;
-            FPS_TD_GET(g, d)
-            if (pos < n) temp[sidx[pos]] = d;
         }
     }
 #undef FPS_TD_GET
 #undef FPS_TD_SET
 }
+
 
 int fps_block(int n) {
     int t = 1;
@@ -2419,18 +2030,7 @@ static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int
     float *stdv = reinterpret_cast<float *>(rest);
     uint32_t *sidx = reinterpret_cast<uint32_t *>(rest + (size_t)b * np * 4);
     uint16_t *cells = reinterpret_cast<uint16_t *>(rest + (size_t)b * np * 8);
-    // A/B switches (same samples): DCLR_FPS_SINGLE = kernel B, one sample per barrier round; DCLR_FPS_PAGED_V2 = kernel B2
-    // (minima in registers, 64-point sub-groups: a third of the traffic, but 20 % slower); default = kernel B
-    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_PAGED_V2") ? 2 : 1;
-    if (mode == 2) {
-        if (np == 32768)
-            hipLaunchKernelGGL((fps_paged2_kernel<32>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, m,
-                               clouds, idx, spts, sidx, cells, group_box, temp);
-        else
-            hipLaunchKernelGGL((fps_paged2_kernel<64>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, m,
-                               clouds, idx, spts, sidx, cells, group_box, temp);
-        return dclr_launch_status();
-    }
+    static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
 #define FPS_PAGED(NG_, MODE_)                                                                                         \
     hipLaunchKernelGGL((fps_paged_kernel<NG_, MODE_>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, \
                        m, clouds, idx, spts, stdv, sidx, cells, group_box, temp)

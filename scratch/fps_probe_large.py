@@ -14,6 +14,5 @@ for pairs, n, npoint in ((8, 65536, 2), (8, 65536, 1024), (32, 65536, 1024), (80
         s.record(); idx, gp, gb = ops.fps_clouds_grouped(x, npoint); t.record(); torch.cuda.synchronize()
         ts.append(s.elapsed_time(t) * 1e3)
     rounds = gb[:, 0, 6].cpu().numpy()
-    print('   sub-group visits per cloud (kernel B2 only): %.0f = %.1f per round' % (gb[:, 0, 7].mean().item(), gb[:, 0, 7].mean().item() / max(rounds.mean(), 1e-9)), ' entry kept: %.0f' % gb[:, 1, 7].mean().item())
     print('%4d clouds x %5d pts -> %4d samples: median %8.1f us  min %8.1f us; rounds per cloud mean %.1f (%.2f samples/round), checksum %d'
           % (2 * pairs, n, npoint, float(np.median(ts)), min(ts), rounds.mean(), (npoint - 1) / max(rounds.mean(), 1e-9), int(idx.long().sum())), flush=True)
