@@ -733,13 +733,31 @@ def run(args):
     ops.TIMER = timer
     copied0 = feeder.bytes_copied if feeder is not None else 0
     fence()
+    host_trace = [] if os.environ.get('DCLR_BENCH_HOSTTRACE') else None    # diagnostics: host time at which each step returned
+    prof = None
+    if os.environ.get('DCLR_BENCH_HOSTTRACE') == '2':                      # ... and a cProfile of the timed loop (slows it)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
         if timer is not None:
             timer.next_step()
+        if host_trace is not None:
+            host_trace.append(time.perf_counter() - t0)
     fence()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import pstats
+        prof.disable()
+        st = pstats.Stats(prof, stream=sys.stderr)
+        rows_ = sorted(st.stats.items(), key=lambda kv: -kv[1][2])[:40]       # by own time
+        for (fn, line, name), (cc, nc, tt, ct, _) in rows_:
+            print('%7.0f us own %7.0f us cum %5d calls  %s:%d %s' % (1e6 * tt, 1e6 * ct, nc, os.path.basename(fn), line, name), file=sys.stderr)
+    if host_trace is not None and rank == 0:
+        print('host trace (us after t0, per step): ' + ' '.join('%.0f' % (1e6 * v) for v in host_trace) +
+              ' | closing fence returned at %.0f' % (1e6 * elapsed), file=sys.stderr)
     ops.TIMER = None
     alone, fps_rounds = None, None
     if timer is not None and rank == 0:

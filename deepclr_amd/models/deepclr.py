@@ -24,7 +24,7 @@ from ..config import Config
 from ..labels import LabelType
 from ..pointnet2 import PointnetSAModuleMSG
 from .base import BaseModel
-from .helper import Conv1dMultiLayer, LinearMultiLayer, PackedCache
+from .helper import Conv1dMultiLayer, LinearMultiLayer, PackedCache, flat_parameters
 
 FEAT = 64          # feature columns of a cloud-feature row (two 32-channel scales)
 
@@ -152,7 +152,7 @@ class MotionEmbeddingBase(nn.Module):
                 'w3p': ops.pack_weight(w3, 128, tile16=True), 'b3': b3.detach().contiguous(),
                 'w2h': ops.pack_weight_f16(w2, 128, 16), 'w3h': ops.pack_weight_f16(w3, 128, 16),
             }
-        return self._cache.get(list(self.parameters()), build)
+        return self._cache.get(flat_parameters(self), build)
 
     def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int) -> torch.Tensor:
         """rows F of [templates..., sources...] -> rows E (pairs*npoint, 264)."""
@@ -252,7 +252,7 @@ class OutputSimple(DeepCLRModule):
                     wp = ops.pack_weight(w, kp)
                 layers.append((wp, b.detach().contiguous(), n, kp))
             return layers
-        return self._cache.get(list(self.conv.parameters()), build)
+        return self._cache.get(flat_parameters(self.conv), build)
 
     def _packed_f16(self):
         def build():
@@ -270,7 +270,7 @@ class OutputSimple(DeepCLRModule):
                     wp = ops.pack_weight_f16(w, kp, 32)
                 layers.append((wp, b.detach().contiguous(), n, kp))
             return layers
-        return self._cache16.get(list(self.conv.parameters()), build)
+        return self._cache16.get(flat_parameters(self.conv), build)
 
     def _fusable(self, layers, rows: int, pairs: int) -> bool:
         """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512. Its grid is
@@ -393,7 +393,7 @@ class _MergePlan:
 
     @staticmethod
     def _version_key(mods):
-        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+        return tuple((p.data_ptr(), p._version) for m in mods for p in flat_parameters(m))
 
     def current(self) -> bool:
         return self._versions == self._version_key(self._keep['mods'])
@@ -578,7 +578,7 @@ class DeepCLR(BaseModel):
         return y if out is None else out.copy_(y)
 
     def _range_key(self):
-        return tuple((p.data_ptr(), p._version) for m in self._merge_layers for p in m.parameters())
+        return tuple((p.data_ptr(), p._version) for m in self._merge_layers for p in flat_parameters(m))
 
     def _range_unchecked(self) -> bool:
         """True until a checked forward has passed for the current weights (any in-place change bumps a version)."""

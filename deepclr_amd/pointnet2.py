@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from .ops import ball_query, furthest_point_sample  # noqa: F401  (index outputs: nothing to differentiate)
-from .models.helper import PackedCache
+from .models.helper import PackedCache, flat_parameters
 
 __all__ = ['PointnetSAModuleMSG', 'furthest_point_sample', 'gather_operation', 'ball_query',
            'grouping_operation', 'GatherOperation', 'GroupingOperation']
@@ -142,7 +142,7 @@ class PointnetSAModuleMSG(nn.Module):
                     layers.append((ops.pack_weight(w, kp), u.conv.bias.detach().contiguous(), w.shape[0], kp))
                 packed.append(layers)
             return packed
-        return self._cache.get(list(self.parameters()), build)
+        return self._cache.get(flat_parameters(self), build)
 
     def sample(self, clouds: torch.Tensor):
         """Furthest point sampling only (the serial stage; the pipelined runner issues it batches ahead
@@ -165,7 +165,7 @@ class PointnetSAModuleMSG(nn.Module):
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':
             # split-f16 operands clamp at +-65504: the first call after the weights changed (or every call with
             # CHECK_RANGE = 'always') also runs the f32 matrix instructions and compares (two host syncs, once)
-            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            key = tuple((p.data_ptr(), p._version) for p in flat_parameters(self))
             if ops.CHECK_RANGE == 'always' or key != self._range_ok:
                 want = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, precision='f32')
                 err, scale = float((rows - want).abs().max()), float(want.abs().max())
@@ -185,7 +185,7 @@ class PointnetSAModuleMSG(nn.Module):
             raise RuntimeError("expected {} feature channels, got {}".format(
                 self._in_feat, 0 if features is None else features.shape[1]))
         if not self.fused or (torch.is_grad_enabled() and (xyz.requires_grad or (features is not None and features.requires_grad)
-                                                           or any(p.requires_grad for p in self.parameters()))
+                                                           or any(p.requires_grad for p in flat_parameters(self)))
                               and self.differentiable):
             return self._forward_composed(xyz, features)
         clouds = xyz if features is None else torch.cat((xyz, features.transpose(1, 2)), dim=2)
@@ -207,7 +207,7 @@ class PointnetSAModuleMSG(nn.Module):
         # go through the HIP operators and their HIP backward; the shared MLP and the max then stay in torch, whose
         # autograd has their backward (rocBLAS GEMMs). Inference keeps dclr_linear with the max folded into the last layer.
         train = torch.is_grad_enabled() and (xyz.requires_grad or (feats is not None and feats.requires_grad)
-                                             or any(p.requires_grad for p in self.parameters()))
+                                             or any(p.requires_grad for p in flat_parameters(self)))
         outs = []
         for radius, nsample, layers, stack in zip(self.radii, self.nsamples, self.packed_mlps() if not train else
                                                   [None] * len(self.radii), self.mlps):
