@@ -107,3 +107,17 @@ __device__ __forceinline__ uint32_t dclr_lanemask_lt_popc(uint64_t mask) {
     // number of set bits of `mask` strictly below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
+
+// ---- batches that travel together without being concatenated (include/deepclr_amd.h, dclr_*_batched): the clouds of a
+// call are `batches` batches of 2 * per clouds each ([templates | sources], the reference's batch layout), batch i at
+// base + i * stride floats; the call numbers them [templates of every batch | sources of every batch]. batches <= 1: plain.
+struct DclrCloudView {
+    int per, batches;
+    long long stride;
+};
+__device__ __forceinline__ size_t dclr_cloud_offset(const DclrCloudView &v, size_t c, size_t cloud_floats) {
+    if (v.batches <= 1) return c * cloud_floats;
+    const size_t half_n = (size_t)v.per * v.batches;        // templates (or sources) in the call
+    const size_t half = c / half_n, r = c % half_n;
+    return (r / v.per) * (size_t)v.stride + (half * v.per + r % v.per) * cloud_floats;
+}

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                                                          float *__restrict__ temp,
                                                          int32_t *__restrict__ idx,
                                                          float4 *__restrict__ group_pts,
-                                                         float *__restrict__ group_box) {
+                                                         float *__restrict__ group_box, DclrCloudView view) {
     constexpr int NW = WGS / 64, NP = WGS * P, BINS = 4096, S = P / G;
     static_assert(P % G == 0 && G <= 16 && NW <= 16 && BINS % WGS == 0, "layout");
     typedef typename VecOf<P>::type vec;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     int32_t *picked = reinterpret_cast<int32_t *>(dyn_lds + BINS + NP / 2);   // shares storage with `cellof`
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    pts += (size_t)blockIdx.x * n * pstride;
+    pts += dclr_cloud_offset(view, blockIdx.x, (size_t)n * pstride);
     idx += (size_t)blockIdx.x * m;
     if (temp) temp += (size_t)blockIdx.x * n;
     if (group_pts) group_pts += (size_t)blockIdx.x * NP;
@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                                                          int32_t *__restrict__ idx, float4 *__restrict__ spts_all,
                                                          float *__restrict__ std_all, uint32_t *__restrict__ sidx_all,
                                                          uint16_t *__restrict__ cell_all, float *__restrict__ group_box,
-                                                         float *__restrict__ temp) {
+                                                         float *__restrict__ temp, DclrCloudView view) {
     constexpr int WGS = 1024, NW = 16, P = 4 * NG, NP = WGS * P, BINS = 4096;
     typedef typename VecOf<NG>::type gvec;
     __shared__ unsigned long long cell[3];
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     extern __shared__ int32_t picked[];
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    pts += (size_t)blockIdx.x * n * pstride;
+    pts += dclr_cloud_offset(view, blockIdx.x, (size_t)n * pstride);
     idx += (size_t)blockIdx.x * m;
     float4 *spts = spts_all + (size_t)blockIdx.x * NP;
     float *std_ = std_all + (size_t)blockIdx.x * NP;
@@ -1935,7 +1935,7 @@ void launch_reg(int b, int n, int pstride, int m, const float *pts, float *temp,
 
 template <int WGS, int P, int G>
 void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, float4 *group_pts,
-                   float *group_box, hipStream_t s) {
+                   float *group_box, hipStream_t s, DclrCloudView view) {
     constexpr int NP = WGS * P;
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
@@ -1945,13 +1945,13 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_WAVECAND") ? 1 : 3;
     if (mode == 0)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 0>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
+                           group_pts, group_box, view);
     else if (mode == 1)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
+                           group_pts, group_box, view);
     else
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 3>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box);
+                           group_pts, group_box, view);
 }
 
 // Spatial groups the pruned kernel forms (and can export): NW waves x G groups of 64 * (P / G) points.
@@ -1967,20 +1967,21 @@ bool fps_group_layout(int n, int *n_groups, int *group_size) {
 }
 
 int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx,
-                 hipStream_t s, float4 *group_pts = nullptr, float *group_box = nullptr) {
+                 hipStream_t s, float4 *group_pts = nullptr, float *group_box = nullptr,
+                 DclrCloudView view = DclrCloudView{0, 1, 0}) {
     DCLR_REQUIRE(b > 0 && n > 0 && m > 0 && pstride >= 3 && pts && idx);
     if ((size_t)m * sizeof(int32_t) > 64 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
     static const bool plain = getenv("DCLR_FPS_PLAIN") != nullptr;             // A/B switch for measurements
     if (!plain && n > 1024 && n <= 16384) {
         // 2048 points: 8 waves x 4 points per lane and two clouds per CU (422 vs 445 us for 512 clouds; 4 waves x 8
         // points, six clouds per CU: 490 -- a round costs the same ~4.6 k cycles whatever the wave count)
-        if (n <= 2048) launch_pruned<512, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
-        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
-        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
-        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s);
+        if (n <= 2048) launch_pruned<512, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
+        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
+        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
+        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
         return dclr_launch_status();
     }
-    if (group_pts || group_box) return DCLR_E_UNSUPPORTED;
+    if (group_pts || group_box || view.batches > 1) return DCLR_E_UNSUPPORTED;
     if (n <= 1024) launch_reg<1024, 1>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 2048) launch_reg<1024, 2>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 4096) launch_reg<1024, 4>(b, n, pstride, m, pts, temp, idx, s);
@@ -2024,7 +2025,7 @@ extern "C" long long dclr_fps_workspace_bytes(int b, int n) {
 // Workspace sampler (16384 < n <= 65536). `spts` = the sorted points (float4 x, y, z, index bits; 1024 * P per cloud): a
 // slice of the workspace, or the caller's group_pts buffer when the groups are exported for set abstraction.
 static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int32_t *idx, float4 *spts, char *rest,
-                            float *group_box, float *temp, hipStream_t stream) {
+                            float *group_box, float *temp, hipStream_t stream, DclrCloudView view = DclrCloudView{0, 1, 0}) {
     if ((size_t)m * sizeof(int32_t) > 32 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] shares LDS with the histogram
     const size_t np = n <= 32768 ? 32768 : 65536;
     float *stdv = reinterpret_cast<float *>(rest);
@@ -2033,7 +2034,7 @@ static int fps_launch_paged(int b, int n, int c, int m, const float *clouds, int
     static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : 1;                 // A/B switch: one sample per barrier round
 #define FPS_PAGED(NG_, MODE_)                                                                                         \
     hipLaunchKernelGGL((fps_paged_kernel<NG_, MODE_>), dim3(b), dim3(1024), (size_t)m * sizeof(int32_t), stream, n, c, \
-                       m, clouds, idx, spts, stdv, sidx, cells, group_box, temp)
+                       m, clouds, idx, spts, stdv, sidx, cells, group_box, temp, view)
     if (np == 32768) { if (mode) FPS_PAGED(8, 1); else FPS_PAGED(8, 0); }
     else             { if (mode) FPS_PAGED(16, 1); else FPS_PAGED(16, 0); }
 #undef FPS_PAGED
@@ -2099,4 +2100,26 @@ extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *
     if (!fps_group_layout(n, &ng, &gs) || getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
     return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
                         group_box);
+}
+
+// The grouped sampler over batches that are NOT concatenated (DclrCloudView, common.h): what the pipelined runner launches
+// for the batches of one sampling group. workspace: as dclr_fps_clouds_grouped_ws for n > 16384, ignored otherwise.
+extern "C" int dclr_fps_clouds_grouped_batched(int b, int n, int c, int m, const float *clouds, int pairs_per_batch,
+                                               int n_batches, long long batch_stride, int32_t *idx, float *group_pts,
+                                               float *group_box, void *workspace, long long workspace_bytes,
+                                               dclr_stream_t stream) {
+    DCLR_REQUIRE(c >= 3 && b > 0 && m > 0 && clouds && idx && group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
+    DCLR_REQUIRE(pairs_per_batch > 0 && n_batches > 0 && batch_stride >= 0 && b == 2 * pairs_per_batch * n_batches);
+    if (getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
+    const DclrCloudView view{pairs_per_batch, n_batches, batch_stride};
+    int ng, gs;
+    if (!fps_group_layout(n, &ng, &gs)) return DCLR_E_UNSUPPORTED;
+    if (n > 16384) {
+        const size_t np = n <= 32768 ? 32768 : 65536;
+        DCLR_REQUIRE(workspace && workspace_bytes >= (long long)((size_t)b * np * 10) && ((uintptr_t)workspace & 15) == 0);
+        return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(group_pts), static_cast<char *>(workspace),
+                                group_box, nullptr, (hipStream_t)stream, view);
+    }
+    return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
+                        group_box, view);
 }

@@ -50,6 +50,7 @@ struct SaParams {
     const float4 *group_pts;                    // optional spatial groups from the sampling kernel (or null)
     const float *group_box;
     int n_groups, group_size;
+    DclrCloudView view;                         // how the call's clouds lie in memory (dclr_sa_msg_fused_batched)
 };
 
 template <int C>
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         bx = (int)(i % gridDim.x);
     }
     const int j0 = (bx * SA_WAVES + wave) * SA_CPW;                  // this wave's first centroid
-    const float *cloud = clouds + bi * (size_t)prm.n * C;
+    const float *cloud = dclr_uniform(clouds + dclr_cloud_offset(prm.view, bi, (size_t)prm.n * C));   // scalar registers
 
     // The workgroup's 16 centroids go to LDS once. Without groups (exhaustive sweep) wave w keeps centroids 4 w .. 4 w + 3
     // for the whole kernel; with groups the waves PULL centroids one at a time (sa_next): a workgroup lives as long as its
@@ -810,13 +811,15 @@ __global__ __launch_bounds__(256) void channels_to_rows_kernel(int npoint, int n
 
 static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx, int n_scales,
                      const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs, float *out_rows,
-                     int32_t *counts, const float *group_pts, const float *group_box, dclr_stream_t stream) {
+                     int32_t *counts, const float *group_pts, const float *group_box, dclr_stream_t stream,
+                     DclrCloudView view = DclrCloudView{0, 1, 0}) {
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
     if (n > 65536) return DCLR_E_UNSUPPORTED;                 // ring entries hold 16-bit point indices
     SaParams prm{};
     prm.n = n; prm.npoint = npoint; prm.n_scales = n_scales;
+    prm.view = view;
     for (int s = 0; s < n_scales; ++s) {
         DCLR_REQUIRE(nsamples_host[s] > 0 && mlp_host_ptrs[s]);
         prm.radius2[s] = radii_host[s] * radii_host[s];
@@ -863,6 +866,16 @@ extern "C" int dclr_sa_msg_fused_f16(int b, int n, int c, int npoint, const floa
                                      dclr_stream_t stream) {
     return sa_launch(true, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
                      counts, group_pts, group_box, stream);
+}
+
+extern "C" int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const float *clouds, int pairs_per_batch,
+                                         int n_batches, long long batch_stride, const int32_t *fps_idx, int n_scales,
+                                         const float *radii_host, const int *nsamples_host,
+                                         const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
+                                         const float *group_pts, const float *group_box, dclr_stream_t stream) {
+    DCLR_REQUIRE(pairs_per_batch > 0 && n_batches > 0 && batch_stride >= 0 && b == 2 * pairs_per_batch * n_batches);
+    return sa_launch(f16 != 0, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
+                     counts, group_pts, group_box, stream, DclrCloudView{pairs_per_batch, n_batches, batch_stride});
 }
 
 extern "C" int dclr_rows_to_channels(int b, int npoint, int nfeat, int xyz_col, int stride, const float *rows,

@@ -87,15 +87,15 @@ class SetAbstraction(DeepCLRModule):
     def output_dim(self) -> int:
         return 3 + self._output_feat_dim
 
-    def sample(self, clouds: torch.Tensor):
-        return self._sa0.sample(clouds)
+    def sample(self, clouds: torch.Tensor, view=None):
+        return self._sa0.sample(clouds, view)
 
-    def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
+    def forward_rows(self, clouds: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """(2B, N, C) point-major clouds -> rows F."""
-        rows = self._sa0.forward_rows(clouds, sample)
+        rows = self._sa0.forward_rows(clouds, sample, view)
         if self._sa1 is None:
             return rows
-        b = clouds.shape[0]
+        b = clouds.shape[0] if view is None else 2 * view[0] * view[1]
         ch = ops.rows_to_channels(rows, b, self._sa0.npoint, self._sa0.out_features())
         xyz, feat = self._sa1(ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous())
         return ops.channels_to_rows(torch.cat((xyz.transpose(1, 2), feat), dim=1).contiguous(), ops.F_STRIDE)
@@ -543,13 +543,15 @@ class DeepCLR(BaseModel):
                     fn()
 
     # -- row-level pipeline (what bench.py and the sharded runner drive) ---------------------------
-    def sample(self, x: torch.Tensor):
-        """(2B, N, C) -> furthest-point sample (indices (2B, npoint) int32 + the kernel's spatial groups)."""
-        return self._cloud_layers[0].sample(x)
+    def sample(self, x: torch.Tensor, view=None):
+        """(2B, N, C) -> furthest-point sample (indices (2B, npoint) int32 + the kernel's spatial groups).
+        view = ops.batch_view(batches): x is the first of several batches that are read where they lie; the result covers
+        all of them in the order [templates of every batch | sources of every batch]."""
+        return self._cloud_layers[0].sample(x, view)
 
-    def cloud_feature_rows(self, x: torch.Tensor, sample=None) -> torch.Tensor:
+    def cloud_feature_rows(self, x: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """(2B, N, C) -> rows F ((2B)*npoint, 68); sample: precomputed self.sample(x), else computed here."""
-        return self._cloud_layers[0].forward_rows(x, sample)
+        return self._cloud_layers[0].forward_rows(x, sample, view)
 
     def merge_prep(self, f_rows: torch.Tensor, pairs: int):
         """The part of merge_rows that needs nothing but the feature rows (per-point halves of flow layer 1, kNN),

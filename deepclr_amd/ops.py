@@ -9,7 +9,7 @@ kernels the model forward uses. Everything runs on the current torch stream.
 """
 import ctypes
 import os
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -188,11 +188,45 @@ def fps_group_layout(n: int):
     return (ng.value, gs.value) if rc == 0 else None
 
 
-def fps_clouds_grouped(clouds: torch.Tensor, npoint: int):
+def batch_view(batches) -> Optional[Tuple[int, int, int]]:
+    """(pairs per batch, number of batches, stride in floats) when the (2B, N, C) batches of one launch lie at a constant
+    stride in memory (the same tensor every time: stride 0; views of one staging chunk; a ring) -- then the grouped sampler
+    and set abstraction read them in place (dclr_*_batched) -- else None (the caller concatenates)."""
+    first = batches[0]
+    if len(batches) < 2 or not first.is_contiguous() or first.dtype != torch.float32 or first.shape[0] % 2:
+        return None
+    stride = batches[1].data_ptr() - first.data_ptr()
+    if stride < 0 or stride % 4 or (0 < stride < first.numel() * 4):
+        return None
+    for i, t in enumerate(batches):
+        if t.shape != first.shape or t.dtype != first.dtype or t.device != first.device or not t.is_contiguous() \
+                or t.data_ptr() != first.data_ptr() + i * stride:
+            return None
+    return first.shape[0] // 2, len(batches), stride // 4
+
+
+def fps_clouds_grouped(clouds: torch.Tensor, npoint: int, view: Optional[Tuple[int, int, int]] = None):
     """Sampling plus the kernel's spatial groups: (idx, group_pts, group_box); the last two are None when
-    the cloud size has no grouped kernel (then set abstraction sweeps exhaustively)."""
+    the cloud size has no grouped kernel (then set abstraction sweeps exhaustively).
+    view = batch_view([...]): `clouds` is the FIRST of several batches read in place; results cover all of them in the
+    concatenated order [templates of every batch | sources of every batch]."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
+    if view is not None:
+        per, nb, stride = view
+        layout = fps_group_layout(n)
+        if layout is None or b != 2 * per or (n > 16384 and npoint * 4 > 32 * 1024):
+            raise RuntimeError("batch view: no grouped sampler for these clouds (concatenate the batches instead)")
+        ng, gs = layout
+        b = 2 * per * nb
+        idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
+        gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
+        gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
+        need = lib.load().dclr_fps_workspace_bytes(b, n) if n > 16384 else 0
+        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device) if need else None
+        _call('dclr_fps_clouds_grouped_batched', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), per, nb,
+              stride, idx.data_ptr(), gpts.data_ptr(), gbox.data_ptr(), lib.ptr(ws), need, lib.stream_ptr())
+        return idx, gpts, gbox
     layout = fps_group_layout(n)
     if layout is None:
         return fps_clouds(clouds, npoint), None, None
@@ -222,12 +256,18 @@ def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor])
 
 
 def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[float], nsamples: Sequence[int],
-                 mlps: List[torch.Tensor], want_counts: bool = False, groups=None, precision: Optional[str] = None):
+                 mlps: List[torch.Tensor], want_counts: bool = False, groups=None, precision: Optional[str] = None,
+                 view: Optional[Tuple[int, int, int]] = None):
     """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)].
     groups: (group_pts, group_box) from fps_clouds_grouped for the same clouds, or None.
-    precision: 'f16x2' (layers 2, 3 of the shared MLP on split-f16 operands) or 'f32'; default ops.PRECISION."""
+    precision: 'f16x2' (layers 2, 3 of the shared MLP on split-f16 operands) or 'f32'; default ops.PRECISION.
+    view: as fps_clouds_grouped (clouds = the first batch, fps_idx / groups cover all batches)."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
+    if view is not None:
+        b = 2 * view[0] * view[1]
+        if fps_idx.shape[0] != b or clouds.shape[0] != 2 * view[0]:
+            raise RuntimeError("batch view: fps_idx must cover all batches of the view")
     npoint = fps_idx.shape[1]
     ns = len(radii)
     out = torch.empty(b * npoint, F_STRIDE, dtype=torch.float32, device=clouds.device)
@@ -235,6 +275,14 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
+    if view is not None:
+        _call('dclr_sa_msg_fused_batched', 'sa_msg_fused[%dx%d]' % (b, n), int((precision or PRECISION) == 'f16x2'), b, n, c,
+              npoint, clouds.data_ptr(), view[0], view[1], view[2], fps_idx.data_ptr(), ns,
+              ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
+              ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
+              None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
+              lib.stream_ptr())
+        return (out, counts) if want_counts else out
     entry = 'dclr_sa_msg_fused_f16' if (precision or PRECISION) == 'f16x2' else 'dclr_sa_msg_fused'
     _call(entry, 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,
                                            ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),

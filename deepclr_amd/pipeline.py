@@ -7,11 +7,13 @@ batches i+1 .. i+depth on side HIP streams while set abstraction, flow embedding
 of batch i run on the main stream (the reference never batches or pipelines: one pair per call,
 /root/reference/deepclr/models/base.py:118-120, scripts/inference.py:100-104).
 """
+import os
 from collections import deque
 from typing import Deque, Iterable, Iterator, Optional, Tuple
 
 import torch
 
+from . import ops
 from .models.deepclr import DeepCLR
 
 
@@ -52,6 +54,7 @@ class PipelinedForward:
         self._ahead = ahead
         self._dense_group = dense_group
         self._inputs_ready = inputs_ready
+        self._in_place = hasattr(model, '_cloud_layers') and os.environ.get('DCLR_BATCH_VIEW', '1') != '0'   # A/B: 0 = always concatenate
         self._hold_launch = False                   # dense groups: a full sampling group is launched right AFTER the next
                                                     # dense launch has been enqueued (the host needs ~0.3 ms for the chain)
         self._group_out = None                      # (batches of the running dense group, their outputs)
@@ -99,8 +102,14 @@ class PipelinedForward:
                     # [templates of every batch | sources of every batch]: the reference's batch layout for
                     # len(xs) * B pairs, so the dense stages can take all of them in one go
                     half = xs[0].shape[0] // 2
-                    big = torch.cat([b[:half] for b in xs] + [b[half:] for b in xs])
-                    rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+                    view = ops.batch_view(xs) if self._in_place else None
+                    if view is not None:
+                        # batches at a constant stride (the same resident tensor, views of one staging chunk): the sampler
+                        # and set abstraction read them where they lie -- no 42 MB concatenation per ten KITTI batches
+                        rows = self._model.cloud_feature_rows(xs[0], self._model.sample(xs[0], view), view)
+                    else:
+                        big = torch.cat([b[:half] for b in xs] + [b[half:] for b in xs])
+                        rows = self._model.cloud_feature_rows(big, self._model.sample(big))
                     prep = self._model.merge_prep(rows, half * len(xs))
                     done = torch.cuda.Event()
                     done.record(side)

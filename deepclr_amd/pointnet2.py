@@ -144,30 +144,31 @@ class PointnetSAModuleMSG(nn.Module):
             return packed
         return self._cache.get(flat_parameters(self), build)
 
-    def sample(self, clouds: torch.Tensor):
+    def sample(self, clouds: torch.Tensor, view=None):
         """Furthest point sampling only (the serial stage; the pipelined runner issues it batches ahead
         on side streams): clouds (B, N, C) -> (idx (B, npoint) int32, group_pts, group_box); the group
-        tensors are the sampling kernel's spatial partition, or None when it has none for this N."""
+        tensors are the sampling kernel's spatial partition, or None when it has none for this N.
+        view = ops.batch_view(batches): `clouds` is the first of several batches read where they lie."""
         if clouds.shape[2] != 3 + self._in_feat:
             raise RuntimeError("expected {} columns per point, got {}".format(3 + self._in_feat, clouds.shape[2]))
         if not self.fused:
             raise NotImplementedError("sample()/forward_rows() belong to the fused kernel; this module runs composed")
-        return ops.fps_clouds_grouped(clouds, self.npoint)
+        return ops.fps_clouds_grouped(clouds, self.npoint, view)
 
-    def forward_rows(self, clouds: torch.Tensor, sample=None) -> torch.Tensor:
+    def forward_rows(self, clouds: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68); sample = self.sample(clouds)."""
         if sample is None:
-            sample = self.sample(clouds)
+            sample = self.sample(clouds, view)
         idx, gpts, gbox = sample
         groups = None if gpts is None else (gpts, gbox)
         mlps = self.packed_mlps()
-        rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups)
+        rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, view=view)
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':
             # split-f16 operands clamp at +-65504: the first call after the weights changed (or every call with
             # CHECK_RANGE = 'always') also runs the f32 matrix instructions and compares (two host syncs, once)
             key = tuple((p.data_ptr(), p._version) for p in flat_parameters(self))
             if ops.CHECK_RANGE == 'always' or key != self._range_ok:
-                want = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, precision='f32')
+                want = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, precision='f32', view=view)
                 err, scale = float((rows - want).abs().max()), float(want.abs().max())
                 if not err <= 1e-4 * max(1.0, scale) or not scale < ops.F16_MAX:
                     raise RuntimeError("split-f16 matrix path out of range in set abstraction: features reach {:.4g} "

@@ -248,6 +248,25 @@ int dclr_sa_msg_fused_f16(int b, int n, int c, int npoint, const float *clouds, 
                           const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
                           const float *group_pts, const float *group_box, dclr_stream_t stream);
 
+/* ---- batches that travel together, not concatenated ------------------------------------------------------
+ * The reference runs one batch per call (/root/reference/deepclr/models/deepclr.py:488-503: x = [templates | sources] of
+ * ONE batch). The pipelined runner puts several batches into one sampling launch and one dense launch; their clouds had
+ * to be concatenated first as [templates of every batch | sources of every batch] (42 MB copied per ten KITTI batches).
+ * These two entries read the batches where they lie instead: the b = 2 * pairs_per_batch * n_batches clouds of the call are
+ * n_batches batches of 2 * pairs_per_batch clouds each ([templates | sources], (2 B, n, c) contiguous), batch i at
+ * clouds + i * batch_stride floats (0: the same batch every time; any constant stride, e.g. a ring of staging buffers);
+ * cloud j of the call = template / source (j / (B g)) of batch (j % (B g)) / B, i.e. all outputs (idx, groups, rows) are in
+ * the concatenated order. n_batches = 1 is the plain call. Grouped sampler: workspace as dclr_fps_clouds_grouped_ws for
+ * n > 16384 (ignored otherwise); set abstraction: f16 != 0 selects dclr_sa_msg_fused_f16. */
+int dclr_fps_clouds_grouped_batched(int b, int n, int c, int m, const float *clouds, int pairs_per_batch, int n_batches,
+                                    long long batch_stride, int32_t *idx, float *group_pts, float *group_box,
+                                    void *workspace, long long workspace_bytes, dclr_stream_t stream);
+int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const float *clouds, int pairs_per_batch,
+                              int n_batches, long long batch_stride, const int32_t *fps_idx, int n_scales,
+                              const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs,
+                              float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
+                              dclr_stream_t stream);
+
 /* ---- the dense stages of one batch in one call ----------------------------------------------------------
  * Rows F of [templates..., sources...] -> pose outputs y (pairs, n_out): the launches DeepCLR.forward makes
  * after set abstraction (reference: deepclr.py:502-506: merge layers = flow embedding, then the pose head)

@@ -580,6 +580,58 @@ def test_pipelined_runner_with_inputs_ready_and_buffer_ring_reuse():
             assert torch.equal(a, b), (depth, group, dense, i)
 
 
+@pytest.mark.parametrize('kind, pairs, n', [('kitti', 2, 2048), ('modelnet', 3, 2048), ('kitti', 1, 16384), ('kitti', 1, 20000)])
+def test_batches_read_in_place_equal_the_concatenated_launch(kind, pairs, n):
+    """dclr_fps_clouds_grouped_batched / dclr_sa_msg_fused_batched: the batches of one launch at a constant stride (views of
+    one chunk; the same tensor again and again) are read where they lie. Sampling indices, groups and feature rows must be
+    those of the launch over the concatenated clouds [templates of every batch | sources of every batch]; batches without
+    a constant stride are not a view."""
+    cfg = synthetic.model_cfg(kind)
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=31))
+    g = 3
+    chunk = torch.stack([torch.from_numpy(synthetic.make_batch(kind, pairs, n, first_pair=4 * i)) for i in range(g)]).to(DEV)
+    for batches in ([chunk[i] for i in range(g)], [chunk[1]] * g):
+        view = ops.batch_view(batches)
+        assert view == (pairs, g, chunk[0].numel() if batches[0] is not batches[1] else 0)
+        big = torch.cat([b[:pairs] for b in batches] + [b[pairs:] for b in batches])
+        with torch.no_grad():
+            want_s = model.sample(big)
+            want = model.cloud_feature_rows(big, want_s)
+            got_s = model.sample(batches[0], view)
+            got = model.cloud_feature_rows(batches[0], got_s, view)
+            alone = model.cloud_feature_rows(batches[0], None, view)           # sampling inside
+        # (the exported groups themselves are not compared: points of one sorting cell land in scatter order)
+        assert torch.equal(got_s[0], want_s[0]) and got_s[1].shape == want_s[1].shape and got_s[2].shape == want_s[2].shape
+        assert torch.equal(got, want) and torch.equal(alone, want)
+    assert ops.batch_view([chunk[0], chunk[2], chunk[1]]) is None               # no constant stride
+    assert ops.batch_view([chunk[0]]) is None and ops.batch_view([chunk[0][:, ::2], chunk[1][:, ::2]]) is None   # not contiguous
+
+
+def test_dense_groups_of_the_runner_read_their_batches_in_place(monkeypatch):
+    """PipelinedForward with dense groups: batches that are views of one chunk go through the in-place launch (no torch.cat
+    of clouds on the way), batches allocated one by one through the concatenating launch; both equal the plain forward."""
+    from deepclr_amd.pipeline import PipelinedForward
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=32))
+    chunk = torch.stack([torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=3 * i)) for i in range(8)]).to(DEV)
+    views = [chunk[i] for i in range(8)]
+    clones = {i: views[i].clone() for i in (3, 0, 2, 1, 7, 4, 6, 5)}           # allocated out of order: no constant stride
+    separate = [clones[i] for i in range(8)]
+    assert ops.batch_view(separate[:4]) is None and ops.batch_view(separate[4:]) is None
+    with torch.no_grad():
+        want = [model(b)[0] for b in separate]
+    cats = []
+    real_cat = torch.cat
+    monkeypatch.setattr(torch, 'cat', lambda ts, *a, **k: cats.append(len(ts)) or real_cat(ts, *a, **k))
+    for batches, expect_cat in ((views, False), (separate, True)):
+        cats.clear()
+        runner = PipelinedForward(model, depth=2, ahead='knn', group=4, dense_group=True, inputs_ready=True)
+        got = list(runner.run(batches))
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (expect_cat, i)
+        assert (8 in cats) == expect_cat, cats                                   # 4 template halves + 4 source halves
+
+
 def test_pipelined_run_prefetches_every_batch_after_the_first(monkeypatch):
     """run() must hand every batch but the first to a side stream (the slice of upcoming batches skipped one
     per window, which was then sampled synchronously on the main stream)."""
@@ -591,8 +643,8 @@ def test_pipelined_run_prefetches_every_batch_after_the_first(monkeypatch):
     on_main = []
     real = type(model).cloud_feature_rows
     monkeypatch.setattr(type(model), 'cloud_feature_rows',
-                        lambda self, x, sample=None: on_main.append(torch.cuda.current_stream().cuda_stream == main)
-                        or real(self, x, sample))
+                        lambda self, x, sample=None, view=None: on_main.append(torch.cuda.current_stream().cuda_stream == main)
+                        or real(self, x, sample, view))
     for depth, group, dense in ((2, 1, False), (3, 1, False), (2, 2, False), (2, 2, True)):
         on_main.clear()
         runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense)
