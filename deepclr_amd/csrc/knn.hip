@@ -17,6 +17,7 @@ constexpr int KNN_WAVES = 4;     // waves per workgroup
 constexpr int KNN_QRUN = 2;      // queries per wave
 constexpr int KNN_MAX_NX = 4096; // candidates staged in LDS (3 * 4 bytes each)
 constexpr uint32_t KNN_INF = 0x7F800000u;
+constexpr float KNN_SLOT_INIT = 1e10f;   // torch-cluster 1.5.9: dist = torch::full(..., 1e10), col = -1
 constexpr int KNN_LIMIT = 40;    // most lanes a selection threshold may let through (fast path of knn_block)
 
 struct KnnXyzSource {            // (clouds*n, 3) packed points
@@ -48,7 +49,9 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
     uint32_t *knn_compact = reinterpret_cast<uint32_t *>(knn_lds + 3 * NXP);    // per wave: 64 distances + 64 indices
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < NXP; i += KNN_WAVES * 64) {
-        float x = 0.f, y = 0.f, z = 0.f;
+        // padding slots lie 3e18 away: their squared distance (~1e37, finite) fails the "< 1e10" test below like any
+        // candidate the published kernel would never insert
+        float x = 3.0e18f, y = 3.0e18f, z = 3.0e18f;
         if (i < nx) cand.load(cand_cloud, nx, i, x, y, z);
         sx[i] = x; sy[i] = y; sz[i] = z;
     }
@@ -71,14 +74,17 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
                 const f2 dx = ax - q2x, dy = ay - q2y, dz = az - q2z;
                 const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
                 const f2 dd = (xx + yy) + zz;
-                d[c] = i < nx ? __float_as_uint(dd[0]) : KNN_INF;
-                d[c + 1] = i + 64 < nx ? __float_as_uint(dd[1]) : KNN_INF;
+                // the published kernel's slots start at 1e10 and take a candidate only if "slot > distance": a candidate
+                // at 1e10 or beyond (or NaN) is never inserted -- its slot stays -1
+                d[c] = dd[0] < KNN_SLOT_INIT ? __float_as_uint(dd[0]) : KNN_INF;
+                d[c + 1] = dd[1] < KNN_SLOT_INIT ? __float_as_uint(dd[1]) : KNN_INF;
             }
         } else {
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int i = c * 64 + lane;
-                d[c] = i < nx ? __float_as_uint(dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz)) : KNN_INF;
+                const float dd = dclr_sqdist(sx[i], sy[i], sz[i], qx, qy, qz);
+                d[c] = dd < KNN_SLOT_INIT ? __float_as_uint(dd) : KNN_INF;
             }
         }
         // Fast path: shrink the problem to <= 64 candidates, one per lane, then run the k arg-min rounds on those.

@@ -133,7 +133,8 @@ def grouping_operation_grad(grad_out: torch.Tensor, idx: torch.Tensor, n: int) -
 
 def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor] = None,
         batch_y: Optional[torch.Tensor] = None, batch_size: Optional[int] = None) -> torch.Tensor:
-    """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index].
+    """``torch_cluster.knn`` for equally sized sorted batches: (2, len(y)*k) int64 = [y index; x index] (fewer columns when
+    a query has fewer than k candidates within a squared distance of 1e10: upstream's slots start there and stay -1).
     The batch count has to be known on the host (it sizes the launch): one device-to-host read of the two batch
     vectors' last entries, none when the caller passes ``batch_size`` (torch_cluster >= 1.6 takes the same argument)."""
     x, y = lib.dev_f32(x, 'x'), lib.dev_f32(y, 'y')
@@ -159,7 +160,10 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor
     col = torch.empty(b * ny * k, dtype=torch.int64, device=x.device)
     _call('dclr_knn', 'knn', b, nx, ny, k, x.data_ptr(), y.data_ptr(), row.data_ptr(), col.data_ptr(),
                                   lib.stream_ptr())
-    return torch.stack((row, col), dim=0)
+    # upstream (torch-cluster 1.5.9, knn_cuda.cu) drops the slots no candidate was inserted into (squared distance
+    # >= 1e10, the slots' initial value): `mask = col != -1` -- a host synchronisation there as here
+    mask = col != -1
+    return torch.stack((row[mask], col[mask]), dim=0)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -164,8 +164,9 @@ void dclr_oracle_group_points(int b, int c, int n, int npoints, int nsample, con
  * batches -- the only form DeepCLR uses (deepclr.py:149-155,164-166).
  * x: (b*nx, 3) candidates, y: (b*ny, 3) queries. Published 1.5.9 GPU kernel,
  * restated: per query, distance accumulates from 0 over the 3 dims of (x - y);
- * a k-slot list (init 1e38 / -1) is kept ascending by insertion with a strict
- * "slot > new" test, so equal distances keep the lower candidate index first.
+ * a k-slot list (init 1e10 / -1, as upstream's torch::full) is kept ascending by insertion with a strict
+ * "slot > new" test, so equal distances keep the lower candidate index first and a
+ * candidate at squared distance 1e10 or beyond (or NaN) is never inserted.
  * row/col are (b*ny*k) int64 with GLOBAL (flattened) indices; unfilled slots
  * are -1 (the Python side drops them, which DeepCLR's .view(2, G, k) cannot
  * survive, so callers need nx >= k).
@@ -178,7 +179,7 @@ void dclr_oracle_knn(int b, int nx, int ny, int k, const float *x, const float *
             const size_t gy = (size_t)bi * ny + qy;
             float dist[64];
             int64_t *r = row + gy * k, *c = col + gy * k;
-            for (int s = 0; s < k; ++s) { dist[s] = 1e38f; c[s] = -1; r[s] = -1; }
+            for (int s = 0; s < k; ++s) { dist[s] = 1e10f; c[s] = -1; r[s] = -1; }
             for (int qx = 0; qx < nx; ++qx) {
                 const size_t gx = (size_t)bi * nx + qx;
                 float d = sqdist3(x[gx * 3 + 0], x[gx * 3 + 1], x[gx * 3 + 2],

@@ -108,6 +108,21 @@ def test_knn_bit_exact(kind, b, nx, ny, k):
     assert torch.equal(got, want)
 
 
+def test_knn_drops_candidates_beyond_the_initial_slot_distance():
+    """torch-cluster 1.5.9 starts its k slots at distance 1e10 / index -1 and inserts on "slot > distance": a candidate at a
+    squared distance of 1e10 or more is never taken and the Python side drops the -1 slots. Queries with 4 near and 4 far
+    candidates and k = 6 come back with 4 neighbours each (DeepCLR's own .view(2, G, k) could not survive that: its clouds
+    never get there); one candidate exactly AT 1e10 is dropped too."""
+    near = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]])
+    far = torch.tensor([[2.0e5, 0, 0], [0, -3.0e5, 0], [1.0e5, 0, 0], [4.0e5, 4.0e5, 0]])       # (1e5)^2 = 1e10 exactly
+    x = torch.cat([near, far, near + 0.5, far * 2]).reshape(-1, 3)                              # two batch items of 8
+    y = torch.tensor([[0.0, 0, 0], [0.1, 0.1, 0.1], [0.0, 0, 0], [0.2, 0, 0]])
+    bx, by = torch.arange(2).repeat_interleave(8), torch.arange(2).repeat_interleave(2)
+    want = oracle.knn(x, y, 6, bx, by)
+    got = ops.knn(x.to(DEV), y.to(DEV), 6, bx.to(DEV), by.to(DEV)).cpu()
+    assert want.shape[1] < 4 * 6 and torch.equal(got, want), (got, want)
+
+
 def test_ops_reject_cpu_tensors_and_bad_sizes():
     with pytest.raises(RuntimeError):
         ops.furthest_point_sample(torch.zeros(1, 8, 3), 4)
