@@ -1408,6 +1408,63 @@ __device__ __forceinline__ void fps_accept_samples(int par, int r, int m, bool l
 // group (registers) and which slot holds it (2 bits per group). A round then reads and writes ~10 % of
 // the cloud instead of all of it (fps_stream_kernel: 1 MB per round through one CU's memory path).
 // ------------------------------------------------------------------------------------------------
+// The same leader step with the acceptance tests side by side (the form fps_pruned_kernel MODE 3 uses): the J best
+// published candidates are extracted first in value order (ties by key), then lane 8 j + i tests candidate j against
+// candidate i < j through the LDS crossbar -- one distance evaluation for all pairs instead of a serial
+// extract -> test -> extract chain with wave-uniform operands. Candidate j joins iff every earlier one did and all its
+// tests pass; same picks as fps_accept_samples.
+template <int J>
+__device__ __forceinline__ void fps_accept_samples_par(int par, int r, int m, bool last_alone, int lane,
+                                                       unsigned long long (*wpk)[16], uint32_t (*wru)[16], FpsCand (*cand)[16],
+                                                       int32_t *picked, float (*plist)[4], int *plist_n) {
+    static_assert(J <= 8, "one (j, i) pair per lane");
+    const unsigned long long e = wpk[par][lane & 15];
+    const uint32_t e_ru = wru[par][lane & 15];
+    const FpsCand w = cand[par][lane & 15];
+    uint32_t e_hi = (uint32_t)(e >> 32), e_lo = (uint32_t)e;
+    int wid[J];
+    uint32_t mv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        mv[j] = dclr_row16_max_u32(e_hi);
+        const uint32_t holders = (uint32_t)__ballot(e_hi == mv[j]) & 0xFFFFu;
+        if ((holders & (holders - 1)) == 0) wid[j] = __builtin_ctz(holders);
+        else wid[j] = (int)(dclr_row16_max_u32(e_hi == mv[j] ? e_lo : 0u) & 15u);
+        const bool mine = (lane & 15) == wid[j];
+        e_hi = mine ? 0u : e_hi;
+        e_lo = mine ? 0u : e_lo;
+    }
+    const int lj = lane >> 3, li = lane & 7;                              // lane 8 j + i: candidate j against candidate i
+    int src_j = wid[0], src_i = wid[0];
+    uint32_t vj = mv[0];
+#pragma unroll
+    for (int u = 1; u < J; ++u) {
+        src_j = lj == u ? wid[u] : src_j;
+        src_i = li == u ? wid[u] : src_i;
+        vj = lj == u ? mv[u] : vj;
+    }
+    const float xj = __shfl(w.x, src_j), yj = __shfl(w.y, src_j), zj = __shfl(w.z, src_j);
+    const float xi = __shfl(w.x, src_i), yi = __shfl(w.y, src_i), zi = __shfl(w.z, src_i);
+    const uint32_t ui = (uint32_t)__shfl((int)e_ru, src_i);
+    const int kj = __shfl(w.k, src_j);
+    const uint32_t dji = __float_as_uint(dclr_sqdist(xj, yj, zj, xi, yi, zi));
+    const bool pair_bad = lj < J && li < lj && !(vj > ui && dji >= vj);
+    const unsigned long long bad = __ballot(pair_bad);                    // bits 8 j .. 8 j + 7: candidate j fails a test
+    int cnt = 1;
+    bool open = true;
+#pragma unroll
+    for (int j = 1; j < J; ++j) {
+        const bool ok = r + j < m && !(last_alone && r + j == m - 1) && ((bad >> (8 * j)) & 0xFFull) == 0ull;
+        open = open && ok;
+        cnt += open ? 1 : 0;
+    }
+    if (lj < J && li == 0 && lj < cnt) {                                  // lanes 0, 8, 16, ...: candidates 0, 1, 2, ...
+        picked[r + lj] = kj;
+        plist[lj][0] = xj; plist[lj][1] = yj; plist[lj][2] = zj;
+    }
+    if (lane == 0) *plist_n = cnt;
+}
+
 // Kernel B: the global group (256 consecutive sorted positions) that is wave w's g-th: neighbours in sorted order go to
 // different waves. (Rotating the assignment from one coarse sorting cell to the next -- 16 g + (w - g) mod 16 -- moved the
 // per-cloud imbalance to other waves and changed nothing: 1471 vs 1456 us per 16 clouds.)
@@ -1603,7 +1660,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         //      value into lane g. Selecting the wave's candidate and runner-up is then a 16-lane reduction over
         //      registers, with no fetch of the winner. gmaxv is the group's exact largest running minimum here. -------
 #ifndef FPS_PAGED_J
-#define FPS_PAGED_J 3
+#define FPS_PAGED_J 4             // samples a barrier round may accept (3: 424 rounds, 4: 370; 1-2 % with the side-by-side leader)
 #endif
 #ifndef FPS_PAGED_B
 #define FPS_PAGED_B 1          // groups in flight per wave: 2 would need 24 bytes of scratch beside the register-resident minima
@@ -1766,7 +1823,11 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
 #ifdef FPS_DEBUG
             FPS_STAMP(q4);
 #endif
+#ifdef FPS_PAGED_SERIAL_LEADER
             if (wave == 0) fps_accept_samples<J>(par, r, m, temp != nullptr, lane, wpk, wru, cand, picked, plist, &plist_n);
+#else
+            if (wave == 0) fps_accept_samples_par<J>(par, r, m, temp != nullptr, lane, wpk, wru, cand, picked, plist, &plist_n);
+#endif
             __syncthreads();
 #ifdef FPS_DEBUG
             FPS_STAMP(q5);
