@@ -280,16 +280,18 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int pstride, in
 __device__ __forceinline__ uint32_t fps_tk1024(uint32_t k) { return ((__brev(k & 1023u) >> 22) << 6) | (k >> 10); }
 __device__ __forceinline__ uint32_t fps_tk1024_inv(uint32_t tk) { return (__brev(tk >> 6) >> 22) | ((tk & 63u) << 10); }
 
-__device__ __forceinline__ float fps_shfl_min(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
+// Wave minimum / maximum of floats (no NaNs) through the DPP reductions of common.h: the bit pattern is mapped to an unsigned
+// key of the same order (sign bit flipped for positives, all bits for negatives). Six dependent ds_bpermute shuffles per
+// reduction were 12 us of the 16384-point sampler's setup once the slice boxes (24 reductions per group) were added.
+__device__ __forceinline__ uint32_t fps_ordered_key(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
-__device__ __forceinline__ float fps_shfl_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
+__device__ __forceinline__ float fps_from_ordered_key(uint32_t k) {
+    return __uint_as_float(k ^ (((k >> 31) - 1u) | 0x80000000u));
 }
+__device__ __forceinline__ float fps_shfl_min(float v) { return fps_from_ordered_key(dclr_wave_min_u32(fps_ordered_key(v))); }
+__device__ __forceinline__ float fps_shfl_max(float v) { return fps_from_ordered_key(dclr_wave_max_u32(fps_ordered_key(v))); }
 
 // Rounded lower bound of dclr_sqdist(p, c) over all p inside the box [lo, hi] (same operation
 // sequence as dclr_sqdist; see the header comment for why it is a bound on the ROUNDED distance).
@@ -383,7 +385,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                                                          float *__restrict__ temp,
                                                          int32_t *__restrict__ idx,
                                                          float4 *__restrict__ group_pts,
-                                                         float *__restrict__ group_box, DclrCloudView view) {
+                                                         float *__restrict__ group_box, DclrCloudView view,
+                                                         float *__restrict__ slice_box) {
     constexpr int NW = WGS / 64, NP = WGS * P, BINS = 4096, S = P / G;
     static_assert(P % G == 0 && G <= 16 && NW <= 16 && BINS % WGS == 0, "layout");
     typedef typename VecOf<P>::type vec;
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     if (temp) temp += (size_t)blockIdx.x * n;
     if (group_pts) group_pts += (size_t)blockIdx.x * NP;
     if (group_box) group_box += (size_t)blockIdx.x * NW * G * 8;
+    if (slice_box) slice_box += (size_t)blockIdx.x * NW * G * S * 8;
 
     // ---- 1. bounding box of the cloud --------------------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -499,6 +503,44 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     int dq[G];                                             // sorted group of this wave's group g (wave-uniform)
 #pragma unroll
     for (int g = 0; g < G; ++g) dq[g] = wave * G + g;
+    // Extent of sorted group q (the wave's contiguous share, before dealing) and, on request, the boxes of its S slices
+    // (slice i = sorted positions [(q S + i) 64, + 64): a compact sub-cell; set abstraction tests them one by one)
+    auto group_extent = [&](int q, float (&d)[3]) {
+        float glo3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ghi3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            const int pos = (q * S + i) * 64 + lane;
+            float lo3[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi3[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            if (pos < n) {
+                const float *pk = pts + (size_t)sbuf[pos] * pstride;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo3[a] = pk[a]; hi3[a] = pk[a]; }
+            }
+            if (slice_box != nullptr && S > 1) {            // wave-uniform
+                float sb[6];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { sb[a] = fps_shfl_min(lo3[a]); sb[3 + a] = fps_shfl_max(hi3[a]); }
+                if (lane < 8)
+                    slice_box[(size_t)(q * S + i) * 8 + lane] =
+                        lane == 0 ? sb[0] : lane == 1 ? sb[1] : lane == 2 ? sb[2] : lane == 3 ? sb[3]
+                        : lane == 4 ? sb[4] : lane == 5 ? sb[5] : 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { glo3[a] = fminf(glo3[a], sb[a]); ghi3[a] = fmaxf(ghi3[a], sb[3 + a]); }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { glo3[a] = fminf(glo3[a], lo3[a]); ghi3[a] = fmaxf(ghi3[a], hi3[a]); }
+            }
+        }
+        const bool reduced = slice_box != nullptr && S > 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] = reduced ? ghi3[a] - glo3[a] : fps_shfl_max(ghi3[a]) - fps_shfl_min(glo3[a]);
+    };
+    if constexpr (!DEALT) {
+        if (slice_box != nullptr && S > 1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) { float d[3]; group_extent(wave * G + g, d); }
+        }
+    }
     if constexpr (DEALT) {
         constexpr int NGR = NW * G;
         static_assert(NGR <= 64, "one group per lane");
@@ -506,19 +548,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int q = wave * G + g;                    // provisional: the wave's contiguous share
-            float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                const int pos = (q * S + i) * 64 + lane;
-                if (pos < n) {
-                    const float *pk = pts + (size_t)sbuf[pos] * pstride;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) { blo[a] = fminf(blo[a], pk[a]); bhi[a] = fmaxf(bhi[a], pk[a]); }
-                }
-            }
             float d[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) d[a] = fps_shfl_max(bhi[a]) - fps_shfl_min(blo[a]);
+            group_extent(q, d);
             if (lane == 0) ghot[q] = d[0] >= 0.f ? d[0] * d[1] + d[1] * d[2] + d[2] * d[0] : -1.0f;   // empty group: last
         }
         __syncthreads();
@@ -563,7 +594,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int pos = slot_pos(g * S + i, lane);
-            tkg[i] = pos < n ? fps_tk1024(sbuf[pos]) : 0xFFFFu;
+            // (key << 2 | run): the sort below orders a lane's slots by tie key; the run a point came from -- 64 consecutive
+            // positions of the sorted cloud, a compact sub-cell -- decides where the EXPORTED copy of it goes
+            tkg[i] = ((pos < n ? fps_tk1024(sbuf[pos]) : 0xFFFFu) << 2) | (uint32_t)i;
         }
 #pragma unroll
         for (int k2 = 2; k2 <= S; k2 <<= 1)
@@ -582,6 +615,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 }
         float blo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
         bool any = false;
+        uint32_t run[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) { run[i] = tkg[i] & 3u; tkg[i] >>= 2; }
 #pragma unroll
         for (int i = 0; i < S; ++i) {
             const int jj = g * S + i;
@@ -598,9 +634,11 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 any = true;
             }
             vec_set<P>(px, jj, x); vec_set<P>(py, jj, y); vec_set<P>(pz, jj, z); vec_set<P>(td, jj, d);
-            if (group_pts) {                                // regrouped copy for the set-abstraction fast path
+            if (group_pts) {
+                // regrouped copy for the set-abstraction fast path, under the SORTED group's number and in RUN order: slice r
+                // of the exported group = the r-th 64 consecutive sorted positions of the group (their boxes: slice_box)
                 const bool ok = tkg[i] != 0xFFFFu;
-                group_pts[(size_t)(wave * G + g) * (64 * S) + i * 64 + lane] =
+                group_pts[(size_t)deal(g) * (64 * S) + run[i] * 64 + lane] =
                     make_float4(ok ? x : 3.0e38f, ok ? y : 3.0e38f, ok ? z : 3.0e38f,
                                 __uint_as_float(ok ? fps_tk1024_inv(tkg[i]) : 0xFFFFFFFFu));
             }
@@ -613,7 +651,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
             box[a] = l; box[3 + a] = h;
         }
         if (group_box && lane < 8)
-            group_box[(size_t)(wave * G + g) * 8 + lane] =
+            group_box[(size_t)deal(g) * 8 + lane] =
                 lane == 0 ? box[0] : lane == 1 ? box[1] : lane == 2 ? box[2] : lane == 3 ? box[3]
                 : lane == 4 ? box[4] : lane == 5 ? box[5] : 0.f;
         gbest[g] = any ? 0.f : -1.0f;
@@ -1996,7 +2034,7 @@ void launch_reg(int b, int n, int pstride, int m, const float *pts, float *temp,
 
 template <int WGS, int P, int G>
 void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx, float4 *group_pts,
-                   float *group_box, hipStream_t s, DclrCloudView view) {
+                   float *group_box, hipStream_t s, DclrCloudView view, float *slice_box) {
     constexpr int NP = WGS * P;
     const size_t tail = (size_t)NP * 2 > (size_t)m * 4 ? (size_t)NP * 2 : (size_t)m * 4;   // cell ids, then picked[]
     const size_t lds = (size_t)4096 * 4 + (size_t)NP * 2 + tail;
@@ -2006,13 +2044,13 @@ void launch_pruned(int b, int n, int pstride, int m, const float *pts, float *te
     static const int mode = getenv("DCLR_FPS_SINGLE") ? 0 : getenv("DCLR_FPS_WAVECAND") ? 1 : 3;
     if (mode == 0)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 0>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box, view);
+                           group_pts, group_box, view, slice_box);
     else if (mode == 1)
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 1>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box, view);
+                           group_pts, group_box, view, slice_box);
     else
         hipLaunchKernelGGL((fps_pruned_kernel<WGS, P, G, 3>), dim3(b), dim3(WGS), lds, s, n, pstride, m, pts, temp, idx,
-                           group_pts, group_box, view);
+                           group_pts, group_box, view, slice_box);
 }
 
 // Spatial groups the pruned kernel forms (and can export): NW waves x G groups of 64 * (P / G) points.
@@ -2029,20 +2067,20 @@ bool fps_group_layout(int n, int *n_groups, int *group_size) {
 
 int fps_dispatch(int b, int n, int pstride, int m, const float *pts, float *temp, int32_t *idx,
                  hipStream_t s, float4 *group_pts = nullptr, float *group_box = nullptr,
-                 DclrCloudView view = DclrCloudView{0, 1, 0}) {
+                 DclrCloudView view = DclrCloudView{0, 1, 0}, float *slice_box = nullptr) {
     DCLR_REQUIRE(b > 0 && n > 0 && m > 0 && pstride >= 3 && pts && idx);
     if ((size_t)m * sizeof(int32_t) > 64 * 1024) return DCLR_E_UNSUPPORTED;   // picked[] lives in LDS
     static const bool plain = getenv("DCLR_FPS_PLAIN") != nullptr;             // A/B switch for measurements
     if (!plain && n > 1024 && n <= 16384) {
         // 2048 points: 8 waves x 4 points per lane and two clouds per CU (422 vs 445 us for 512 clouds; 4 waves x 8
         // points, six clouds per CU: 490 -- a round costs the same ~4.6 k cycles whatever the wave count)
-        if (n <= 2048) launch_pruned<512, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
-        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
-        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
-        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view);
+        if (n <= 2048) launch_pruned<512, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view, slice_box);
+        else if (n <= 4096) launch_pruned<1024, 4, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view, slice_box);
+        else if (n <= 8192) launch_pruned<1024, 8, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view, slice_box);
+        else launch_pruned<1024, 16, 4>(b, n, pstride, m, pts, temp, idx, group_pts, group_box, s, view, slice_box);
         return dclr_launch_status();
     }
-    if (group_pts || group_box || view.batches > 1) return DCLR_E_UNSUPPORTED;
+    if (group_pts || group_box || slice_box || view.batches > 1) return DCLR_E_UNSUPPORTED;
     if (n <= 1024) launch_reg<1024, 1>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 2048) launch_reg<1024, 2>(b, n, pstride, m, pts, temp, idx, s);
     else if (n <= 4096) launch_reg<1024, 4>(b, n, pstride, m, pts, temp, idx, s);
@@ -2167,8 +2205,8 @@ extern "C" int dclr_fps_clouds_grouped(int b, int n, int c, int m, const float *
 // for the batches of one sampling group. workspace: as dclr_fps_clouds_grouped_ws for n > 16384, ignored otherwise.
 extern "C" int dclr_fps_clouds_grouped_batched(int b, int n, int c, int m, const float *clouds, int pairs_per_batch,
                                                int n_batches, long long batch_stride, int32_t *idx, float *group_pts,
-                                               float *group_box, void *workspace, long long workspace_bytes,
-                                               dclr_stream_t stream) {
+                                               float *group_box, float *slice_box, void *workspace,
+                                               long long workspace_bytes, dclr_stream_t stream) {
     DCLR_REQUIRE(c >= 3 && b > 0 && m > 0 && clouds && idx && group_pts && group_box && ((uintptr_t)group_pts & 15) == 0);
     DCLR_REQUIRE(pairs_per_batch > 0 && n_batches > 0 && batch_stride >= 0 && b == 2 * pairs_per_batch * n_batches);
     if (getenv("DCLR_FPS_PLAIN")) return DCLR_E_UNSUPPORTED;
@@ -2176,11 +2214,13 @@ extern "C" int dclr_fps_clouds_grouped_batched(int b, int n, int c, int m, const
     int ng, gs;
     if (!fps_group_layout(n, &ng, &gs)) return DCLR_E_UNSUPPORTED;
     if (n > 16384) {
+        if (slice_box) return DCLR_E_UNSUPPORTED;           // the workspace kernel exports no slice boxes
         const size_t np = n <= 32768 ? 32768 : 65536;
         DCLR_REQUIRE(workspace && workspace_bytes >= (long long)((size_t)b * np * 10) && ((uintptr_t)workspace & 15) == 0);
         return fps_launch_paged(b, n, c, m, clouds, idx, reinterpret_cast<float4 *>(group_pts), static_cast<char *>(workspace),
                                 group_box, nullptr, (hipStream_t)stream, view);
     }
+    if (slice_box && gs <= 64) return DCLR_E_UNSUPPORTED;   // one slice per group: the group box is the slice box
     return fps_dispatch(b, n, c, m, clouds, nullptr, idx, (hipStream_t)stream, reinterpret_cast<float4 *>(group_pts),
-                        group_box, view);
+                        group_box, view, slice_box);
 }

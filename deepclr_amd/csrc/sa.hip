@@ -39,6 +39,9 @@ constexpr int SA_TILE = 256;                    // points per LDS tile (one tile
 constexpr int SA_RING = 512;                    // ring capacity: < 64 left over + one centroid's neighbours (fast path) or
                                                 // + 4 slices staged between drain checks (sweep); power of two
 constexpr int SA_MAX_SCALES = 2;
+#ifndef SA_SLICE_STEP
+#define SA_SLICE_STEP 6                         // slices fetched together on the slice path (8: 32 bytes of scratch beside the drain)
+#endif
 constexpr int SA_H1 = 16, SA_H2 = 16, SA_OUT = 32;
 
 struct SaParams {
@@ -51,6 +54,7 @@ struct SaParams {
     const float *group_box;
     int n_groups, group_size;
     DclrCloudView view;                         // how the call's clouds lie in memory (dclr_sa_msg_fused_batched)
+    const float *slice_box;                     // optional (<= 64 groups of > 64 points): boxes of the groups' 64-point slices
 };
 
 template <int C>
@@ -278,7 +282,7 @@ __device__ __forceinline__ float sa_box_lower_bound(float lx, float ly, float lz
 }
 
 
-template <int C, int NCH, bool F16>
+template <int C, int NCH, bool F16, bool SL = false>     // SL: slice boxes present (NCH == 1): the scan works slice by slice
 __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                                                                const float *__restrict__ clouds,
                                                                const int32_t *__restrict__ fps_idx,
@@ -331,6 +335,28 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         const int mlp_floats = SA_H1 * C + SA_H1 + SA_H2 * SA_H1 + SA_H2 + SA_OUT * SA_H2 + SA_OUT;
         for (int s = 0; s < prm.n_scales; ++s)
             for (int i = tid; i < mlp_floats; i += SA_WAVES * 64) sa_w[s][i] = prm.mlp[s][i];
+    }
+    // The boxes of the cloud's 64-point slices (<= 256), as f16 pairs {min, max} per axis, rounded OUTWARD (a larger box
+    // keeps the bound a bound): 3 KB in the sweep's tile, which is idle whenever there are groups (its first 1 KB serves
+    // the crowded-centroid histogram). One 32-byte load per thread, overlapped with the centroid fetches above.
+    uint32_t *sa_sbx = reinterpret_cast<uint32_t *>(&sa_tile[0][0]) + 256;       // [3][256]: axis, slice
+    constexpr bool use_slices = SL && NCH == 1;
+    if constexpr (use_slices) {
+        const int n_slices = prm.n_groups * (prm.group_size / 64);
+        if (tid < n_slices) {
+            const float4 *sb = reinterpret_cast<const float4 *>(prm.slice_box + (bi * n_slices + tid) * 8);
+            const float4 b0 = sb[0], b1 = sb[1];                                   // min x y z, max x | max y z
+            const float lo3[3] = {b0.x, b0.y, b0.z}, hi3[3] = {b0.w, b1.x, b1.y};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                _Float16 hl = (_Float16)lo3[a], hh = (_Float16)hi3[a];
+                uint16_t bl = __builtin_bit_cast(uint16_t, hl), bh = __builtin_bit_cast(uint16_t, hh);
+                // one step towards -inf / +inf where the nearest f16 landed inside the box
+                if ((float)hl > lo3[a]) bl = (bl & 0x7FFFu) == 0 ? (uint16_t)0x8001u : (bl & 0x8000u) ? (uint16_t)(bl + 1) : (uint16_t)(bl - 1);
+                if ((float)hh < hi3[a]) bh = (bh & 0x7FFFu) == 0 ? (uint16_t)0x0001u : (bh & 0x8000u) ? (uint16_t)(bh - 1) : (uint16_t)(bh + 1);
+                sa_sbx[a * 256 + tid] = (uint32_t)bl | ((uint32_t)bh << 16);
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -476,7 +502,76 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
             };
             bool over = false;
             int ch = 0;
-            for (uint64_t m = gm[0]; !over;) {
+            // One loaded slice of 64 candidate points against the centroid: hits are counted and staged (any order)
+            auto scan_slice = [&](const float4 &qq) {
+                // padding slots of a group hold x = y = z = 3e38: their distance is +inf, never a hit
+                const float d2 = dclr_sqdist(cx, cy, cz, qq.x, qq.y, qq.z);
+                if (__ballot(d2 < prm.radius2_max) == 0) return;           // most slices: nothing inside the largest ball
+#pragma unroll
+                for (int s = 0; s < SA_MAX_SCALES; ++s) {
+                    if (s >= prm.n_scales) break;
+                    const bool hit = d2 < prm.radius2[s];
+                    const uint64_t mask = __ballot(hit);
+                    if (mask != 0) {
+                        const int add = __builtin_popcountll(mask);
+                        n1[s] += add;
+                        if (qn[s] + 64 > SA_RING) {            // a slice adds <= 64 entries: never onto live ones
+                            over = true;                       // crowded centroid (> ~450 neighbours): in-order sweep
+                        } else {
+                            const int pre = (int)dclr_lanemask_lt_popc(mask);
+                            if (hit)
+                                sa_ring[wave][s][(qhead[s] + qn[s] + pre) & (SA_RING - 1)] =
+                                    ((uint32_t)c << 16) | (__float_as_uint(qq.w) & 0xFFFFu);
+                            qn[s] += add;
+                        }
+                    }
+                }
+            };
+            if constexpr (use_slices) {
+                {
+                    // Slice level: the reachable groups' slices are tested against the ball (lane 4 h + i: slice i of the
+                    // h-th reachable group, boxes from LDS) and only slices that can hold a neighbour are fetched, six at
+                    // a time whatever groups they belong to -- on the bench clouds 5.8 slices per centroid instead of the
+                    // 20 of its 5 reachable groups: one dependent fetch step instead of three.
+                    const int lps = slices == 4 ? 2 : 1;                   // log2(slices per group): 4 or 2
+                    for (uint64_t mg = gm[0]; mg != 0 && !over;) {
+                        int myg = -1;
+                        const int hh = lane >> lps, per = 64 >> lps;       // groups per round of 64 lanes
+                        for (int h = 0; h < per && mg != 0; ++h) {
+                            const int g = __builtin_ctzll(mg);
+                            mg &= mg - 1;
+                            myg = hh == h ? g : myg;
+                        }
+                        bool shit = false;
+                        if (myg >= 0) {
+                            const int sl = (myg << lps) | (lane & (slices - 1));
+                            const uint32_t bxw = sa_sbx[sl], byw = sa_sbx[256 + sl], bzw = sa_sbx[512 + sl];
+                            auto lo_of = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
+                            auto hi_of = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); };
+                            shit = sa_box_lower_bound(lo_of(bxw), lo_of(byw), lo_of(bzw), hi_of(bxw), hi_of(byw), hi_of(bzw),
+                                                      cx, cy, cz) < prm.radius2_max;
+                        }
+                        for (uint64_t sm = __ballot(shit); sm != 0 && !over;) {
+                            float4 q[SA_SLICE_STEP];
+                            int nq = 0;
+#pragma unroll
+                            for (int u = 0; u < SA_SLICE_STEP; ++u) {
+                                if (sm != 0) {                             // wave-uniform
+                                    const int L = __builtin_ctzll(sm);
+                                    sm &= sm - 1;
+                                    const int g = __builtin_amdgcn_readlane(myg, L);
+                                    q[u] = gp[(size_t)g * prm.group_size + (L & (slices - 1)) * 64 + lane];
+                                    nq = u + 1;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < SA_SLICE_STEP; ++u)
+                                if (u < nq) scan_slice(q[u]);
+                        }
+                    }
+                }
+            }
+            for (uint64_t m = use_slices ? 0ull : gm[0]; !over;) {
                 if constexpr (NCH > 1) {
                     while (m == 0 && ch + 1 < NCH) {           // next chunk of 64 groups (wave-uniform)
                         ++ch;
@@ -812,7 +907,7 @@ __global__ __launch_bounds__(256) void channels_to_rows_kernel(int npoint, int n
 static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx, int n_scales,
                      const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs, float *out_rows,
                      int32_t *counts, const float *group_pts, const float *group_box, dclr_stream_t stream,
-                     DclrCloudView view = DclrCloudView{0, 1, 0}) {
+                     DclrCloudView view = DclrCloudView{0, 1, 0}, const float *slice_box = nullptr) {
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
@@ -832,17 +927,26 @@ static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clo
         if (dclr_fps_group_layout(n, &prm.n_groups, &prm.group_size) != DCLR_OK || prm.n_groups > 256) return DCLR_E_INVALID;
         prm.group_pts = reinterpret_cast<const float4 *>(group_pts);
         prm.group_box = group_box;
+        if (slice_box) {
+            // slice boxes: <= 64 groups of 128 or 256 points (<= 256 slices: one per thread, 3 KB of LDS)
+            if (prm.n_groups > 64 || (prm.group_size != 128 && prm.group_size != 256)) return DCLR_E_UNSUPPORTED;
+            DCLR_REQUIRE(((uintptr_t)slice_box & 15) == 0);
+            prm.slice_box = slice_box;
+        }
+    } else {
+        DCLR_REQUIRE(slice_box == nullptr);
     }
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);
     const int nch = prm.n_groups <= 64 ? 1 : 4;      // chunks of 64 group boxes per lane (128 groups: two of the four stay empty)
-#define SA_LAUNCH(C_, NCH_, F_)                                                                                          \
-    hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_, F_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds,    \
+#define SA_LAUNCH(C_, NCH_, F_, SL_)                                                                                     \
+    hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_, F_, SL_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds, \
                        fps_idx, out_rows, counts)
 #define SA_LAUNCH_C(C_)                                                                                                  \
     do {                                                                                                                 \
-        if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true); else SA_LAUNCH(C_, 4, true); }                                  \
-        else     { if (nch == 1) SA_LAUNCH(C_, 1, false); else SA_LAUNCH(C_, 4, false); }                                \
+        if (prm.slice_box) { if (f16) SA_LAUNCH(C_, 1, true, true); else SA_LAUNCH(C_, 1, false, true); }                \
+        else if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true, false); else SA_LAUNCH(C_, 4, true, false); }               \
+        else          { if (nch == 1) SA_LAUNCH(C_, 1, false, false); else SA_LAUNCH(C_, 4, false, false); }             \
     } while (0)
     if (c == 4) SA_LAUNCH_C(4); else SA_LAUNCH_C(3);
 #undef SA_LAUNCH_C
@@ -872,10 +976,11 @@ extern "C" int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoin
                                          int n_batches, long long batch_stride, const int32_t *fps_idx, int n_scales,
                                          const float *radii_host, const int *nsamples_host,
                                          const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
-                                         const float *group_pts, const float *group_box, dclr_stream_t stream) {
+                                         const float *group_pts, const float *group_box, const float *slice_box,
+                                         dclr_stream_t stream) {
     DCLR_REQUIRE(pairs_per_batch > 0 && n_batches > 0 && batch_stride >= 0 && b == 2 * pairs_per_batch * n_batches);
     return sa_launch(f16 != 0, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
-                     counts, group_pts, group_box, stream, DclrCloudView{pairs_per_batch, n_batches, batch_stride});
+                     counts, group_pts, group_box, stream, DclrCloudView{pairs_per_batch, n_batches, batch_stride}, slice_box);
 }
 
 extern "C" int dclr_rows_to_channels(int b, int npoint, int nfeat, int xyz_col, int stride, const float *rows,

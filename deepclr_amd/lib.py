@@ -34,8 +34,8 @@ SIGNATURES = {
     'dclr_fps_clouds_grouped': [_i, _i, _i, _i, _p, _p, _p, _p, _p],
     'dclr_sa_msg_fused': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_sa_msg_fused_f16': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
-    'dclr_fps_clouds_grouped_batched': [_i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _p, _p, _p, ctypes.c_longlong, _p],
-    'dclr_sa_msg_fused_batched': [_i, _i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dclr_fps_clouds_grouped_batched': [_i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _p, _p, _p, _p, ctypes.c_longlong, _p],
+    'dclr_sa_msg_fused_batched': [_i, _i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_channels_to_rows': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],

@@ -33,6 +33,7 @@ PRECISION = os.environ.get('DCLR_PRECISION', 'f16x2')
 #                      two disagree or an activation leaves the range: a new checkpoint cannot clamp silently on first use;
 #   'always' (or '1')  every forward does (debugging; halves throughput);
 #   'never' (or '0')   no check.
+SLICE_BOXES = os.environ.get('DCLR_SLICE_BOXES', '1') != '0'    # A/B: 0 = set abstraction tests whole 256-point groups only
 CHECK_RANGE = {'1': 'always', '0': 'never'}.get(os.environ.get('DCLR_CHECK_RANGE', 'first'),
                                                 os.environ.get('DCLR_CHECK_RANGE', 'first'))
 F16_MAX = 65504.0
@@ -210,45 +211,47 @@ def batch_view(batches) -> Optional[Tuple[int, int, int]]:
 
 
 def fps_clouds_grouped(clouds: torch.Tensor, npoint: int, view: Optional[Tuple[int, int, int]] = None):
-    """Sampling plus the kernel's spatial groups: (idx, group_pts, group_box); the last two are None when
-    the cloud size has no grouped kernel (then set abstraction sweeps exhaustively).
+    """Sampling plus the kernel's spatial groups: (idx, group_pts, group_box, slice_box); the last three are None when
+    the cloud size has no grouped kernel (then set abstraction sweeps exhaustively), slice_box alone where the groups are
+    single 64-point slices or come from the workspace kernel (n > 16384).
     view = batch_view([...]): `clouds` is the FIRST of several batches read in place; results cover all of them in the
     concatenated order [templates of every batch | sources of every batch]."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
+    layout = fps_group_layout(n)
     if view is not None:
         per, nb, stride = view
-        layout = fps_group_layout(n)
         if layout is None or b != 2 * per or (n > 16384 and npoint * 4 > 32 * 1024):
             raise RuntimeError("batch view: no grouped sampler for these clouds (concatenate the batches instead)")
-        ng, gs = layout
         b = 2 * per * nb
-        idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
-        gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
-        gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
-        need = lib.load().dclr_fps_workspace_bytes(b, n) if n > 16384 else 0
-        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device) if need else None
-        _call('dclr_fps_clouds_grouped_batched', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), per, nb,
-              stride, idx.data_ptr(), gpts.data_ptr(), gbox.data_ptr(), lib.ptr(ws), need, lib.stream_ptr())
-        return idx, gpts, gbox
-    layout = fps_group_layout(n)
-    if layout is None:
-        return fps_clouds(clouds, npoint), None, None
+    elif layout is None or (n > 16384 and npoint * 4 > 32 * 1024):
+        return fps_clouds(clouds, npoint), None, None, None
+    else:
+        # one batch: the plain call is the batched one with a single batch (odd cloud counts: no template / source halves)
+        per, nb, stride = (b // 2, 1, 0) if b % 2 == 0 else (0, 0, 0)
     ng, gs = layout
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
     gpts = torch.empty(b, ng * gs, 4, dtype=torch.float32, device=clouds.device)
     gbox = torch.empty(b, ng, 8, dtype=torch.float32, device=clouds.device)
-    if n > 16384:                        # workspace kernel: its sorted point list is group_pts itself
-        if npoint * 4 > 32 * 1024:
-            return fps_clouds(clouds, npoint), None, None
-        need = lib.load().dclr_fps_workspace_bytes(b, n)
-        ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device)
-        _call('dclr_fps_clouds_grouped_ws', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(),
-              gpts.data_ptr(), gbox.data_ptr(), ws.data_ptr(), need, lib.stream_ptr())
-        return idx, gpts, gbox
-    _call('dclr_fps_clouds_grouped', 'fps_clouds[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
-          gbox.data_ptr(), lib.stream_ptr())
-    return idx, gpts, gbox
+    what = 'fps_clouds[%dx%d]' % (b, n)
+    if nb == 0:                           # odd number of clouds: the older entry points (no slice boxes)
+        if n > 16384:
+            need = lib.load().dclr_fps_workspace_bytes(b, n)
+            ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device)
+            _call('dclr_fps_clouds_grouped_ws', what, b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
+                  gbox.data_ptr(), ws.data_ptr(), need, lib.stream_ptr())
+        else:
+            _call('dclr_fps_clouds_grouped', what, b, n, c, npoint, clouds.data_ptr(), idx.data_ptr(), gpts.data_ptr(),
+                  gbox.data_ptr(), lib.stream_ptr())
+        return idx, gpts, gbox, None
+    sbox = None
+    if n <= 16384 and gs > 64 and SLICE_BOXES:
+        sbox = torch.empty(b, ng * (gs // 64), 8, dtype=torch.float32, device=clouds.device)
+    need = lib.load().dclr_fps_workspace_bytes(b, n) if n > 16384 else 0
+    ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=clouds.device) if need else None
+    _call('dclr_fps_clouds_grouped_batched', what, b, n, c, npoint, clouds.data_ptr(), per, nb, stride, idx.data_ptr(),
+          gpts.data_ptr(), gbox.data_ptr(), lib.ptr(sbox), lib.ptr(ws), need, lib.stream_ptr())
+    return idx, gpts, gbox, sbox
 
 
 def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -263,7 +266,7 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
                  mlps: List[torch.Tensor], want_counts: bool = False, groups=None, precision: Optional[str] = None,
                  view: Optional[Tuple[int, int, int]] = None):
     """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)].
-    groups: (group_pts, group_box) from fps_clouds_grouped for the same clouds, or None.
+    groups: (group_pts, group_box[, slice_box]) from fps_clouds_grouped for the same clouds, or None.
     precision: 'f16x2' (layers 2, 3 of the shared MLP on split-f16 operands) or 'f32'; default ops.PRECISION.
     view: as fps_clouds_grouped (clouds = the first batch, fps_idx / groups cover all batches)."""
     clouds = lib.dev_f32(clouds, 'clouds')
@@ -279,13 +282,16 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     radii_h = (ctypes.c_float * ns)(*[float(r) for r in radii])
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
+    sbox = groups[2] if groups is not None and len(groups) > 2 else None
+    if view is None and sbox is not None and b % 2 == 0:
+        view = (b // 2, 1, 0)                                     # the batched entry with one batch = the plain call
     if view is not None:
         _call('dclr_sa_msg_fused_batched', 'sa_msg_fused[%dx%d]' % (b, n), int((precision or PRECISION) == 'f16x2'), b, n, c,
               npoint, clouds.data_ptr(), view[0], view[1], view[2], fps_idx.data_ptr(), ns,
               ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
               ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
               None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
-              lib.stream_ptr())
+              lib.ptr(sbox), lib.stream_ptr())
         return (out, counts) if want_counts else out
     entry = 'dclr_sa_msg_fused_f16' if (precision or PRECISION) == 'f16x2' else 'dclr_sa_msg_fused'
     _call(entry, 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,

@@ -146,7 +146,7 @@ class PointnetSAModuleMSG(nn.Module):
 
     def sample(self, clouds: torch.Tensor, view=None):
         """Furthest point sampling only (the serial stage; the pipelined runner issues it batches ahead
-        on side streams): clouds (B, N, C) -> (idx (B, npoint) int32, group_pts, group_box); the group
+        on side streams): clouds (B, N, C) -> (idx (B, npoint) int32, group_pts, group_box, slice_box); the group
         tensors are the sampling kernel's spatial partition, or None when it has none for this N.
         view = ops.batch_view(batches): `clouds` is the first of several batches read where they lie."""
         if clouds.shape[2] != 3 + self._in_feat:
@@ -159,8 +159,8 @@ class PointnetSAModuleMSG(nn.Module):
         """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68); sample = self.sample(clouds)."""
         if sample is None:
             sample = self.sample(clouds, view)
-        idx, gpts, gbox = sample
-        groups = None if gpts is None else (gpts, gbox)
+        idx, gpts, gbox = sample[:3]
+        groups = None if gpts is None else (gpts, gbox) + tuple(sample[3:4])      # (+ slice boxes where the sampler exports them)
         mlps = self.packed_mlps()
         rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, view=view)
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':

@@ -260,12 +260,17 @@ int dclr_sa_msg_fused_f16(int b, int n, int c, int npoint, const float *clouds, 
  * n > 16384 (ignored otherwise); set abstraction: f16 != 0 selects dclr_sa_msg_fused_f16. */
 int dclr_fps_clouds_grouped_batched(int b, int n, int c, int m, const float *clouds, int pairs_per_batch, int n_batches,
                                     long long batch_stride, int32_t *idx, float *group_pts, float *group_box,
-                                    void *workspace, long long workspace_bytes, dclr_stream_t stream);
+                                    float *slice_box, void *workspace, long long workspace_bytes, dclr_stream_t stream);
 int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const float *clouds, int pairs_per_batch,
                               int n_batches, long long batch_stride, const int32_t *fps_idx, int n_scales,
                               const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs,
                               float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
-                              dclr_stream_t stream);
+                              const float *slice_box, dclr_stream_t stream);
+/* slice_box (optional, groups of more than 64 points, n <= 16384): (b, n_groups * group_size / 64, 8) f32, the boxes
+ * (min xyz, max xyz, 0, 0) of the 64-point slices of every exported group -- a group's points are exported slice by slice,
+ * slice r = the r-th 64 consecutive points of the spatially sorted cloud inside the group. Set abstraction tests a
+ * centroid's ball against the slices of the groups it reaches and loads only those that can hold a neighbour (a quarter of
+ * the points on the bench clouds). */
 
 /* ---- the dense stages of one batch in one call ----------------------------------------------------------
  * Rows F of [templates..., sources...] -> pose outputs y (pairs, n_out): the launches DeepCLR.forward makes

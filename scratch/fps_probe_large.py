@@ -6,12 +6,12 @@ from deepclr_amd import ops, synthetic
 dev = 'cuda:0'
 for pairs, n, npoint in ((8, 65536, 2), (8, 65536, 1024), (32, 65536, 1024), (80, 65536, 1024), (8, 32768, 1024)):
     x = torch.from_numpy(synthetic.make_batch('kitti', pairs, n)).to(dev)
-    idx, gp, gb = ops.fps_clouds_grouped(x, npoint)
+    idx, gp, gb = ops.fps_clouds_grouped(x, npoint)[:3]
     torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(); idx, gp, gb = ops.fps_clouds_grouped(x, npoint); t.record(); torch.cuda.synchronize()
+        s.record(); idx, gp, gb = ops.fps_clouds_grouped(x, npoint)[:3]; t.record(); torch.cuda.synchronize()
         ts.append(s.elapsed_time(t) * 1e3)
     rounds = gb[:, 0, 6].cpu().numpy()
     print('%4d clouds x %5d pts -> %4d samples: median %8.1f us  min %8.1f us; rounds per cloud mean %.1f (%.2f samples/round), checksum %d'

@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     }
     std::vector<float> w(2 * 896);
     for (auto &v : w) v = u(rng);
-    float *d, *gp, *gb, *rows, *wd; int32_t *idx;
+    float *d, *gp, *gb, *rows, *wd, *sb = nullptr; int32_t *idx;
     int ng = 64, gs = 256;
     dclr_fps_group_layout(n, &ng, &gs);
     hipMalloc(&d, h.size() * 4); hipMalloc(&idx, (size_t)b * m * 4); hipMalloc(&gp, (size_t)b * ng * gs * 16);
@@ -46,6 +46,9 @@ int main(int argc, char **argv) {
         void *ws; const long long need = dclr_fps_workspace_bytes(b, n);
         hipMalloc(&ws, need);
         rc = dclr_fps_clouds_grouped_ws(b, n, c, m, d, idx, gp, gb, ws, need, nullptr);
+    } else if (getenv("SA_SLICES") && gs > 64 && b % 2 == 0) {
+        hipMalloc(&sb, (size_t)b * ng * (gs / 64) * 32);
+        rc = dclr_fps_clouds_grouped_batched(b, n, c, m, d, b / 2, 1, 0, idx, gp, gb, sb, nullptr, 0, nullptr);
     } else {
         rc = dclr_fps_clouds_grouped(b, n, c, m, d, idx, gp, gb, nullptr);
     }
@@ -58,7 +61,8 @@ int main(int argc, char **argv) {
         { static std::vector<unsigned long long> z(16384 * 8, 0); hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg_w), z.data(), z.size() * 8); }
         hipEventRecord(e0);
         const bool f16 = getenv("SA_F32") == nullptr;
-        int rc2 = (f16 ? dclr_sa_msg_fused_f16 : dclr_sa_msg_fused)(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
+        int rc2 = sb ? dclr_sa_msg_fused_batched(f16, b, n, c, m, d, b / 2, 1, 0, idx, 2, radii, ns, mlps, rows, nullptr, gp, gb, sb, nullptr)
+                     : (f16 ? dclr_sa_msg_fused_f16 : dclr_sa_msg_fused)(b, n, c, m, d, idx, 2, radii, ns, mlps, rows, nullptr, use_groups ? gp : nullptr,
                                     use_groups ? gb : nullptr, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);

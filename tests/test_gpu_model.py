@@ -148,6 +148,9 @@ def test_fused_stages_against_oracle(kind, n, pairs):
     (3, 2048, 100, (0.3, 0.6), (64, 128)),      # dense: every neighbourhood overflows its cap, drains mid-sweep
     (4, 1500, 37, (0.25, 5.0), (16, 700)),      # one scale sparse, one that swallows half the cloud; ragged tail
     (4, 777, 64, (0.05,), (8,)),                # single scale
+    (4, 6000, 90, (0.4, 1.0), (24, 64)),        # groups of 128 points: two slices per group (slice boxes)
+    (4, 16384, 128, (0.5, 1.0), (512, 1024)),   # groups of 256 points: four slices per group, the model's own shapes
+    (3, 12000, 77, (0.2, 0.7), (16, 40)),       # four slices, ragged last group, 3 channels
 ])
 def test_fused_set_abstraction_dense_neighbourhoods(c, n, npoint, radii, nsamples):
     _check_set_abstraction(c, n, npoint, radii, nsamples)
@@ -177,8 +180,9 @@ def _check_set_abstraction(c, n, npoint, radii, nsamples, expect_cap=True):
         new_xyz, feat = sam(xyz.to(DEV), None if feats is None else feats.to(DEV))
     assert torch.equal(new_xyz.cpu(), new_xyz_o)
     _close(feat, feat_o)
-    fps, gpts, gbox = ops.fps_clouds_grouped(x.to(DEV), npoint)
+    fps, gpts, gbox, sbox = ops.fps_clouds_grouped(x.to(DEV), npoint)
     assert torch.equal(fps, ops.fps_clouds(x.to(DEV), npoint)) and (gpts is not None) == (n > 1024)
+    assert (sbox is not None) == (gpts is not None and ops.fps_group_layout(n)[1] > 64 and x.shape[0] % 2 == 0)
     rows_a, counts = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True)
     rows_f32, counts_f32 = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(), want_counts=True,
                                             precision='f32')
@@ -189,6 +193,18 @@ def _check_set_abstraction(c, n, npoint, radii, nsamples, expect_cap=True):
                                             want_counts=True, groups=(gpts, gbox))
         assert torch.equal(counts, counts_b)
         assert torch.equal(rows_a, rows_b)
+        if sbox is not None:
+            # slice level: the exported groups lie slice by slice (64 consecutive points of the sorted cloud each), the slice
+            # boxes are their exact bounding boxes, and the slice-by-slice scan finds the same neighbours
+            rows_c, counts_c = ops.sa_msg_fused(x.to(DEV), fps, list(radii), list(nsamples), sam.packed_mlps(),
+                                                want_counts=True, groups=(gpts, gbox, sbox))
+            assert torch.equal(counts, counts_c) and torch.equal(rows_a, rows_c)
+            sl = gpts.view(x.shape[0], -1, 64, 4)
+            live = sl[..., 3].contiguous().view(torch.int32) >= 0
+            for a in range(3):
+                lo = torch.where(live, sl[..., a], torch.full_like(sl[..., a], 3.0e38)).min(dim=2).values
+                hi = torch.where(live, sl[..., a], torch.full_like(sl[..., a], -3.0e38)).max(dim=2).values
+                assert torch.equal(sbox[..., a], lo) and torch.equal(sbox[..., 3 + a], hi)
         k = gpts[..., 3].contiguous().view(torch.int32)   # the groups are a permutation of the cloud
         for b_ in range(x.shape[0]):
             kk = k[b_][k[b_] >= 0].long()
@@ -210,7 +226,7 @@ def test_large_cloud_groups_from_the_workspace_sampler(n, pairs, c):
     sa = {k_: v[0] for k_, v in cfg['params']['cloud_features']['params'].items()}
     x = torch.from_numpy(synthetic.make_batch('kitti', pairs, n, first_pair=41)[:, :, :c].copy()).to(DEV)
     npoint = int(sa['npoint'])
-    idx, gpts, gbox = ops.fps_clouds_grouped(x, npoint)
+    idx, gpts, gbox = ops.fps_clouds_grouped(x, npoint)[:3]
     assert gpts is not None and ops.fps_group_layout(n) == ((128 if n <= 32768 else 256), 256)
     assert torch.equal(idx, ops.fps_clouds(x, npoint))
     k = gpts[..., 3].contiguous().view(torch.int32)
@@ -692,7 +708,7 @@ def test_ring_scan_clouds_crowded_neighbourhoods_match_the_oracle(n, expect_capp
     x_np = synthetic.make_batch('ring', 1, n, first_pair=2)
     x = torch.from_numpy(x_np).to(DEV)
     sa = model._cloud_layers[0]._sa0
-    fps, gpts, gbox = ops.fps_clouds_grouped(x, 1024)
+    fps, gpts, gbox = ops.fps_clouds_grouped(x, 1024)[:3]
     xyz = torch.from_numpy(x_np[:, :, :3]).contiguous()
     fps_o = oracle.furthest_point_sample(xyz, 1024)
     assert torch.equal(fps.cpu(), fps_o)
