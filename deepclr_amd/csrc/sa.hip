@@ -90,6 +90,7 @@ __shared__ __attribute__((aligned(16))) float sa_w[SA_MAX_SCALES][SA_MLP_FLOATS]
 __device__ unsigned long long sa_dbg_w[16384][8];   // per wave, cycles: [0] total, [1] fast path incl. drains, [2] drains,
                                                    // [3] #drains, [4] sweep, [5] 1, [6] drain: point load, [7] drain: MLP + fold
 __shared__ unsigned long long sa_dbg_l[4][2];
+__device__ int getenv_dbg2 = 0;                    // harness switch: 1 = slice-path stamps in slots 4, 6, 7
 #define SA_STAMP(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
 #endif
 
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
 #ifdef SA_DEBUG
     if (lane == 0) { sa_dbg_l[wave][0] = 0; sa_dbg_l[wave][1] = 0; }
     unsigned long long t_begin, t_fast = 0, t_drain = 0, n_drain = 0, t_sweep = 0;
+    unsigned long long t_pre = 0, t_scan = 0, t_rows = 0;      // slice path: pull + box / slice tests; fetch + scan; row writes
     SA_STAMP(t_begin);
 #endif
     // rows of the slots in use: the pooled features, the centroid, the counts; then the slots are free again
@@ -420,7 +422,13 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                 }
             }
         drain_all(true);
+#ifdef SA_DEBUG
+        unsigned long long r0, r1; SA_STAMP(r0);
+#endif
         write_rows();
+#ifdef SA_DEBUG
+        SA_STAMP(r1); t_rows += r1 - r0;
+#endif
     };
 
     // ---- fast path over the sampling kernel's spatial groups ---------------------------------------
@@ -448,6 +456,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         int c = 0;                                             // next free slot
 #pragma unroll 1
         for (;;) {
+#ifdef SA_DEBUG
+            unsigned long long p0, p1, p2; SA_STAMP(p0); p1 = p0; p2 = p0;
+#endif
             int pulled = 0;
             if (lane == 0) pulled = atomicAdd(&sa_next, 1);
             pulled = __builtin_amdgcn_readfirstlane(pulled);
@@ -551,6 +562,9 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                             shit = sa_box_lower_bound(lo_of(bxw), lo_of(byw), lo_of(bzw), hi_of(bxw), hi_of(byw), hi_of(bzw),
                                                       cx, cy, cz) < prm.radius2_max;
                         }
+#ifdef SA_DEBUG
+                        SA_STAMP(p1);
+#endif
                         for (uint64_t sm = __ballot(shit); sm != 0 && !over;) {
                             float4 q[SA_SLICE_STEP];
                             int nq = 0;
@@ -571,6 +585,10 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                     }
                 }
             }
+#ifdef SA_DEBUG
+            SA_STAMP(p2);
+            if (use_slices) { t_pre += p1 - p0; t_scan += p2 - p1; }
+#endif
             for (uint64_t m = use_slices ? 0ull : gm[0]; !over;) {
                 if constexpr (NCH > 1) {
                     while (m == 0 && ch + 1 < NCH) {           // next chunk of 64 groups (wave-uniform)
@@ -636,11 +654,21 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         // Exact, and one crowded centroid costs its workgroup a quarter of what it cost the wave that drew it (the
         // LiDAR near field: 2-6 % of the centroids, each worth 10-20 ordinary ones). Round 2 sent the whole workgroup
         // through all N points instead.
+#ifdef SA_DEBUG
+        unsigned long long f0, f1, f2; SA_STAMP(f0);
+#endif
         finish_slots();                                        // the ordinary centroids of this wave: last drains, rows
         done = 0;
 #pragma unroll
         for (int u = 0; u < SA_CPW; ++u) { jrow[u] = -1; cnt[u][0] = 0; cnt[u][1] = 0; }
+#ifdef SA_DEBUG
+        SA_STAMP(f1);
+#endif
         __syncthreads();
+#ifdef SA_DEBUG
+        SA_STAMP(f2);
+        if (lane == 0) { sa_dbg_l[wave][0] = f1 - f0; sa_dbg_l[wave][1] = f2 - f1; }       // last finish, wait for the other waves
+#endif
         const int n_crowd = sa_ncrowd;                         // the same in every wave from here on
         uint32_t *shist = reinterpret_cast<uint32_t *>(&sa_tile[0][0]);       // 256 shared bins (the sweep's tile is idle here)
 #pragma unroll 1
@@ -873,6 +901,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         unsigned long long *o = sa_dbg_w[(blockIdx.y * gridDim.x + blockIdx.x) * SA_WAVES + wave];
         o[0] = t_end - t_begin; o[1] = t_fast; o[2] = t_drain; o[3] = n_drain; o[4] = t_sweep; o[5] = 1ull;
         o[6] = sa_dbg_l[wave][0]; o[7] = sa_dbg_l[wave][1];
+        if (t_pre != 0 && getenv_dbg2) { o[4] = t_rows; o[6] = t_pre; o[7] = t_scan; }  // slice path: reported in place of sweep / drain detail
     }
 #endif
 }

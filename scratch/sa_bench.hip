@@ -56,6 +56,7 @@ int main(int argc, char **argv) {
     const float radii[2] = {modelnet ? 0.1f : 0.5f, modelnet ? 0.2f : 1.0f}; const int ns[2] = {modelnet ? 256 : 512, modelnet ? 512 : 1024};
     const float *mlps[2] = {wd, wd + 896};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    { int one = getenv("SA_DBG2") ? 1 : 0; hipMemcpyToSymbol(HIP_SYMBOL(getenv_dbg2), &one, sizeof(one)); }
     for (int rep = 0; rep < 3; ++rep) {
         unsigned long long zero[8] = {0};
         { static std::vector<unsigned long long> z(16384 * 8, 0); hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg_w), z.data(), z.size() * 8); }
