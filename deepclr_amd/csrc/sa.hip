@@ -28,6 +28,7 @@
 // Slots that would only repeat the first hit are skipped: max() over a multiset equals max() over
 // its support, so the result is identical. A centroid with no hit reproduces the published
 // behaviour (zero-filled index row => every slot is point 0).
+#include <stdlib.h>
 #include "mma16f.h"
 
 namespace {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
     // the crowded-centroid histogram). One 32-byte load per thread, overlapped with the centroid fetches above.
     uint32_t *sa_sbx = reinterpret_cast<uint32_t *>(&sa_tile[0][0]) + 256;       // [3][256]: axis, slice
     constexpr bool use_slices = SL && NCH == 1;
-    if constexpr (use_slices) {
+    if (use_slices && prm.slice_box != nullptr) {          // (groups of a single slice: the group box is the slice box)
         const int n_slices = prm.n_groups * (prm.group_size / 64);
         if (tid < n_slices) {
             const float4 *sb = reinterpret_cast<const float4 *>(prm.slice_box + (bi * n_slices + tid) * 8);
@@ -544,17 +545,25 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
                     // h-th reachable group, boxes from LDS) and only slices that can hold a neighbour are fetched, six at
                     // a time whatever groups they belong to -- on the bench clouds 5.8 slices per centroid instead of the
                     // 20 of its 5 reachable groups: one dependent fetch step instead of three.
-                    const int lps = slices == 4 ? 2 : 1;                   // log2(slices per group): 4 or 2
+                    // (groups of ONE slice -- clouds of up to 4096 points -- skip the slice test: lane g = group g, and the
+                    // reachable groups are fetched six at a time instead of two)
+                    const int lps = slices == 4 ? 2 : slices == 2 ? 1 : 0;   // log2(slices per group)
                     for (uint64_t mg = gm[0]; mg != 0 && !over;) {
                         int myg = -1;
-                        const int hh = lane >> lps, per = 64 >> lps;       // groups per round of 64 lanes
-                        for (int h = 0; h < per && mg != 0; ++h) {
-                            const int g = __builtin_ctzll(mg);
-                            mg &= mg - 1;
-                            myg = hh == h ? g : myg;
-                        }
                         bool shit = false;
-                        if (myg >= 0) {
+                        if (lps == 0) {                                     // wave-uniform
+                            myg = lane;
+                            shit = ((mg >> lane) & 1ull) != 0;
+                            mg = 0;
+                        } else {
+                            const int hh = lane >> lps, per = 64 >> lps;   // groups per round of 64 lanes
+                            for (int h = 0; h < per && mg != 0; ++h) {
+                                const int g = __builtin_ctzll(mg);
+                                mg &= mg - 1;
+                                myg = hh == h ? g : myg;
+                            }
+                        }
+                        if (lps != 0 && myg >= 0) {
                             const int sl = (myg << lps) | (lane & (slices - 1));
                             const uint32_t bxw = sa_sbx[sl], byw = sa_sbx[256 + sl], bzw = sa_sbx[512 + sl];
                             auto lo_of = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
@@ -968,12 +977,15 @@ static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clo
     constexpr int per_wg = SA_WAVES * SA_CPW;
     dim3 grid((npoint + per_wg - 1) / per_wg, b);
     const int nch = prm.n_groups <= 64 ? 1 : 4;      // chunks of 64 group boxes per lane (128 groups: two of the four stay empty)
+    // slice-granular fetches: with slice boxes, or where a group IS one slice (A/B: DCLR_SA_PAIRS=1 keeps two groups per step)
+    static const bool pairs_only = getenv("DCLR_SA_PAIRS") != nullptr;
+    const bool slice_path = prm.slice_box != nullptr || (prm.group_pts && nch == 1 && prm.group_size == 64 && !pairs_only);
 #define SA_LAUNCH(C_, NCH_, F_, SL_)                                                                                     \
     hipLaunchKernelGGL((sa_msg_kernel<C_, NCH_, F_, SL_>), grid, dim3(SA_WAVES * 64), 0, (hipStream_t)stream, prm, clouds, \
                        fps_idx, out_rows, counts)
 #define SA_LAUNCH_C(C_)                                                                                                  \
     do {                                                                                                                 \
-        if (prm.slice_box) { if (f16) SA_LAUNCH(C_, 1, true, true); else SA_LAUNCH(C_, 1, false, true); }                \
+        if (slice_path) { if (f16) SA_LAUNCH(C_, 1, true, true); else SA_LAUNCH(C_, 1, false, true); }                   \
         else if (f16) { if (nch == 1) SA_LAUNCH(C_, 1, true, false); else SA_LAUNCH(C_, 4, true, false); }               \
         else          { if (nch == 1) SA_LAUNCH(C_, 1, false, false); else SA_LAUNCH(C_, 4, false, false); }             \
     } while (0)
