@@ -60,15 +60,7 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     const float *x = a->colmax;
     for (int l = 0; l < a->n_fc; ++l) {
         float *out = l == a->n_fc - 1 ? a->y : a->fc_tmp[l & 1];
-        // Wide layers on the f32 matrix instruction when the caller packed their weights and padded the row buffers to a
-        // multiple of 64 (the one-wave-per-column kernel stages 8 rows per workgroup: 49 us per layer at 256 rows, 5 % of
-        // the ModelNet step); the last layer (8 columns, pose activation) stays with it.
-        if (a->fc_wp[l] && a->fc_rows >= a->pairs && a->fc_rows % 64 == 0 && a->fc_n[l] % 32 == 0 && a->fc_act[l] <= 1 &&
-            a->fc_k[l] % 8 == 0 && l < a->n_fc - 1)
-            rc = dclr_linear(a->fc_rows, a->fc_n[l], a->fc_k[l], x, a->fc_k[l], a->fc_wp[l], a->fc_b[l], a->fc_act[l], out,
-                             a->fc_n[l], nullptr, 0, stream);
-        else
-            rc = dclr_fc(a->pairs, a->fc_n[l], a->fc_k[l], x, a->fc_w[l], a->fc_b[l], a->fc_act[l], out, stream);
+        rc = dclr_fc(a->pairs, a->fc_n[l], a->fc_k[l], x, a->fc_w[l], a->fc_b[l], a->fc_act[l], out, stream);
         if (rc != DCLR_OK) return rc;
         mark();
         x = out;

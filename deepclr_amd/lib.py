@@ -69,7 +69,6 @@ class MergeArgs(ctypes.Structure):
         ('head_w', _p * MERGE_MAX_LAYERS), ('head_b', _p * MERGE_MAX_LAYERS),
         ('fc_w', _p * MERGE_MAX_FC), ('fc_b', _p * MERGE_MAX_FC),
         ('pt', _p), ('ps', _p), ('knn_idx', _p), ('e_rows', _p), ('colmax', _p), ('fc_tmp', _p * 2), ('y', _p),
-        ('fc_wp', _p * MERGE_MAX_FC), ('fc_rows', _i),
     ]
 
 

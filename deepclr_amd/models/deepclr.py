@@ -232,20 +232,9 @@ class OutputSimple(DeepCLRModule):
         self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
         self._cache = PackedCache()
         self._cache16 = PackedCache()
-        self._cache_fc = PackedCache()
 
     def output_dim(self) -> int:
         return self._label_type.dim
-
-    def _packed_fc(self):
-        """The fully connected layers' weights in the f32 matrix instruction's fragment order (None where a layer does not
-        qualify: columns not a multiple of 32, inputs not a multiple of 8)."""
-        mods = [m.affine for m in self.linear.layers()] + [self.output]
-
-        def build():
-            return [ops.pack_weight(m.weight, m.weight.shape[1]) if m.weight.shape[0] % 32 == 0 and m.weight.shape[1] % 8 == 0
-                    else None for m in mods]
-        return self._cache_fc.get([p for m in mods for p in (m.weight, m.bias) if p is not None], build)
 
     def _packed(self):
         def build():
@@ -293,26 +282,6 @@ class OutputSimple(DeepCLRModule):
                 and all(n % 32 == 0 for _, _, n, _ in layers) and all(kp <= 512 for _, _, _, kp in layers)
                 and all(n <= 512 for _, _, n, _ in layers[:-1]))
 
-    def _fc_tail(self, g: torch.Tensor) -> torch.Tensor:
-        """(pairs, width) pooled features -> (pairs, label_dim): the fully connected layers exactly as dclr_merge_forward
-        runs them (wide layers on the matrix instruction over rows padded to a multiple of 64, the last one per column), so
-        that a pair's result does not depend on which path it took."""
-        packed = self._packed_fc() if os.environ.get('DCLR_FC_MFMA', '1') != '0' else None
-        mods = [m.affine for m in self.linear.layers()]
-        if packed is None or any(m.bias is None for m in mods):
-            return ops.fc(self.linear(g), self.output.weight, self.output.bias, act=self._act)
-        pairs = g.shape[0]
-        rows = (pairs + 63) // 64 * 64
-        x = g
-        for m, wp in zip(mods, packed):
-            if wp is None:
-                x = ops.fc(x[:pairs].contiguous(), m.weight, m.bias, act=1)
-                continue
-            if x.shape[0] != rows:
-                x = torch.cat((x, x.new_zeros(rows - x.shape[0], x.shape[1])))
-            x = ops.linear(x, wp, m.bias, m.weight.shape[0], m.weight.shape[1], relu=True)
-        return ops.fc(x[:pairs].contiguous(), self.output.weight, self.output.bias, act=self._act)
-
     def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
         layers = self._packed()
         if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
@@ -320,13 +289,15 @@ class OutputSimple(DeepCLRModule):
                 g = ops.head_conv_fused_f16(e_rows, ops.E_STRIDE, self._packed_f16(), pairs)
             else:
                 g = ops.head_conv_fused(e_rows, layers, pairs)               # conv chain + max over points
-            return self._fc_tail(g)
+            g = self.linear(g)
+            return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
         h = e_rows
         for wp, b, n, kp in layers[:-1]:
             h = ops.linear(h, wp, b, n, kp, relu=True, ldy=(n + 7) // 8 * 8)
         wp, b, n, kp = layers[-1]
         g = ops.linear(h, wp, b, n, kp, relu=True, colmax_groups=pairs)      # conv + max over points
-        return self._fc_tail(g)
+        g = self.linear(g)
+        return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """(B, 259, P) -> (B, label_dim)."""
@@ -456,19 +427,11 @@ class _MergePlan:
         a.w2, a.w3 = (p['w2h'] if f16 else p['w2p']).data_ptr(), (p['w3h'] if f16 else p['w3p']).data_ptr()
         a.b2, a.b3 = p['b2'].data_ptr(), p['b3'].data_ptr()
         width = max(w.shape[0] for w, _, _ in fcs)
-        # fully connected layers wide enough for the matrix instruction: packed weights (cached with the head's), row buffers
-        # padded to a multiple of 64 rows (zeroed once: rows beyond `pairs` only ever feed rows beyond `pairs`)
-        fc_rows = (pairs + 63) // 64 * 64
-        packed_fc = head._packed_fc() if os.environ.get('DCLR_FC_MFMA', '1') != '0' else [None] * len(fcs)
-        keep['tensors'].append(packed_fc)
-        for i, wp in enumerate(packed_fc):
-            a.fc_wp[i] = None if wp is None or i == len(fcs) - 1 else wp.data_ptr()
-        a.fc_rows = fc_rows
         ws = {'pt': torch.empty(rows, 128, device=device), 'ps': torch.empty(rows, 128, device=device),
               'knn': torch.empty(pairs, npoint, flow._k, dtype=torch.int32, device=device),
               'e': torch.empty(rows, ops.E_STRIDE, device=device),
-              'colmax': torch.zeros(fc_rows, layers[-1][2], device=device),
-              'tmp': torch.zeros(2, fc_rows, width, device=device)}
+              'colmax': torch.empty(pairs, layers[-1][2], device=device),
+              'tmp': torch.empty(2, pairs, width, device=device)}
         keep['ws'] = ws
         a.pt, a.ps, a.knn_idx, a.e_rows = ws['pt'].data_ptr(), ws['ps'].data_ptr(), ws['knn'].data_ptr(), ws['e'].data_ptr()
         a.colmax = ws['colmax'].data_ptr()

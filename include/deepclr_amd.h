@@ -306,11 +306,6 @@ typedef struct DclrMergeArgs {
     float *colmax;                          /* workspace (pairs, head_n[last]) */
     float *fc_tmp[2];                       /* workspace (pairs, max fc width) each */
     float *y;                               /* out (pairs, fc_n[last]) */
-    /* optional: fully connected layers through the matrix instructions. fc_wp[l] = dclr_pack_weight(fc_w[l], kp = fc_k[l])
-     * for layers with fc_n[l] % 32 == 0 and fc_act[l] <= 1 (NULL: the one-wave-per-column kernel, as for the last layer);
-     * fc_rows = rows allocated in colmax and fc_tmp, a multiple of 64 >= pairs (rows beyond `pairs` are scratch). */
-    const float *fc_wp[DCLR_MERGE_MAX_FC];
-    int fc_rows;
 } DclrMergeArgs;
 int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
 
