@@ -343,10 +343,14 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
     // the crowded-centroid histogram). One 32-byte load per thread, overlapped with the centroid fetches above.
     uint32_t *sa_sbx = reinterpret_cast<uint32_t *>(&sa_tile[0][0]) + 256;       // [3][256]: axis, slice
     constexpr bool use_slices = SL && NCH == 1;
-    if (use_slices && prm.slice_box != nullptr) {          // (groups of a single slice: the group box is the slice box)
-        const int n_slices = prm.n_groups * (prm.group_size / 64);
+    // More than 64 groups (the workspace sampler's 128 / 256): the GROUP boxes are staged the same way (f16, outward), so
+    // that a centroid's box tests read LDS instead of 24 floats per lane from L2 -- one dependent round trip per centroid.
+    const bool stage_group_boxes = NCH > 1 && prm.group_box != nullptr && prm.n_groups <= 256;
+    if ((use_slices && prm.slice_box != nullptr) || stage_group_boxes) {   // (groups of a single slice: no slice boxes)
+        const int n_slices = stage_group_boxes ? prm.n_groups : prm.n_groups * (prm.group_size / 64);
         if (tid < n_slices) {
-            const float4 *sb = reinterpret_cast<const float4 *>(prm.slice_box + (bi * n_slices + tid) * 8);
+            const float4 *sb = reinterpret_cast<const float4 *>((stage_group_boxes ? prm.group_box : prm.slice_box) +
+                                                                (bi * n_slices + tid) * 8);
             const float4 b0 = sb[0], b1 = sb[1];                                   // min x y z, max x | max y z
             const float lo3[3] = {b0.x, b0.y, b0.z}, hi3[3] = {b0.w, b1.x, b1.y};
 #pragma unroll
@@ -446,6 +450,16 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         // (with one chunk the boxes stay in registers for the wave's four centroids; with 2 / 4 chunks they are re-read per
         // centroid -- 6 L2-resident loads per chunk -- rather than held across the drain calls: 128 registers per wave)
         auto load_box = [&](int ch, float (&bb)[6]) {
+            if (NCH > 1 && stage_group_boxes) {               // wave-uniform
+                const int g = ch * 64 + lane;
+                const bool have = g < prm.n_groups;
+                const uint32_t bxw = sa_sbx[have ? g : 0], byw = sa_sbx[256 + (have ? g : 0)], bzw = sa_sbx[512 + (have ? g : 0)];
+                auto lo_of = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); };
+                auto hi_of = [](uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); };
+                bb[0] = have ? lo_of(bxw) : 3.0e38f; bb[1] = have ? lo_of(byw) : 3.0e38f; bb[2] = have ? lo_of(bzw) : 3.0e38f;
+                bb[3] = have ? hi_of(bxw) : -3.0e38f; bb[4] = have ? hi_of(byw) : -3.0e38f; bb[5] = have ? hi_of(bzw) : -3.0e38f;
+                return;
+            }
             const bool have = ch * 64 + lane < prm.n_groups;
             const float *gb = prm.group_box + (bi * prm.n_groups + (have ? ch * 64 + lane : 0)) * 8;
 #pragma unroll
