@@ -34,6 +34,9 @@ int main(int argc, char **argv) {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long dbg[16];
         hipMemcpyFromSymbol(dbg, HIP_SYMBOL(fps_dbg), sizeof(dbg));
+        { unsigned long long st[8]; hipMemcpyFromSymbol(st, HIP_SYMBOL(fps_dbg_setup), sizeof(st));
+          printf("   setup (cycles, cloud 0 thread 0): bounding box %llu | cells + sort %llu | rank groups + slice boxes %llu | load groups %llu\n",
+                 st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3]); }
         const double rounds = m - 1;
         printf("rc=%d  %.1f us | active groups/round %.2f of 64 | cycles/round wave0/cloud0: update+publish %.0f barrier-wait %.0f combine %.0f total %.0f\n",
                rc, ms * 1e3, dbg[0] / (rounds * b), dbg[1] / rounds, dbg[2] / rounds, dbg[3] / rounds, dbg[4] / rounds);
