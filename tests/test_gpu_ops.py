@@ -24,6 +24,10 @@ def _cloud(kind, b, n, seed):
         x = degenerate_batch((b + 1) // 2, n, 3, seed)[:b]
     elif kind == 'grid':                      # lattice: many equal distances between distinct points
         x = rng.integers(0, 6, size=(b, n, 3)).astype(np.float32)
+    elif kind == 'line':                      # stretched along one axis: all 12 sorting-cell bits go to x (no key table)
+        x = (rng.normal(size=(b, n, 3)) * np.array([500.0, 0.01, 0.002])).astype(np.float32)
+    elif kind == 'sheet':                     # a thin sheet: 6 + 6 + 0 bits (the LiDAR case), far from the origin
+        x = (rng.uniform(-1, 1, size=(b, n, 3)) * np.array([80.0, 60.0, 0.05]) + np.array([1000.0, -2000.0, 3.0])).astype(np.float32)
     return torch.from_numpy(np.ascontiguousarray(x))
 
 
@@ -34,6 +38,7 @@ def _cloud(kind, b, n, seed):
     ('normal', 1, 20000, 200), ('kitti', 1, 65536, 150), ('grid', 1, 40000, 100),
     ('normal', 2, 1025, 300), ('dup', 2, 2049, 400), ('grid', 3, 16383, 600), ('kitti', 2, 8193, 1100),
     ('grid', 2, 9000, 9000),
+    ('line', 2, 3000, 200), ('line', 2, 16384, 300), ('line', 1, 40000, 200), ('sheet', 2, 5000, 300), ('sheet', 1, 30000, 200),
     # a last group of one or two points that is not the first group of its wave (its box lane holds no point)
     ('kitti', 2, 1089, 64), ('kitti', 2, 2113, 64), ('kitti', 2, 4225, 64), ('kitti', 2, 8449, 64), ('kitti', 2, 8192 + 512 + 2, 64),
     ('normal', 2, 12288 + 768 + 1, 64),
