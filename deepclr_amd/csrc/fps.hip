@@ -463,17 +463,15 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #endif
     // ---- 1. bounding box of the cloud --------------------------------------------------------------
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    float first_x[P], first_y[P], first_z[P];              // the thread's P points stay in registers for the cell pass (step 2)
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
+        first_x[j] = first_y[j] = first_z[j] = 0.f;
         if (k < n) {
-            float v3[3];
-            fps_load_xyz(pts, (size_t)k, pstride, vec4, v3[0], v3[1], v3[2]);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = fminf(lo[a], v3[a]);
-                hi[a] = fmaxf(hi[a], v3[a]);
-            }
+            fps_load_xyz(pts, (size_t)k, pstride, vec4, first_x[j], first_y[j], first_z[j]);
+            lo[0] = fminf(lo[0], first_x[j]); lo[1] = fminf(lo[1], first_y[j]); lo[2] = fminf(lo[2], first_z[j]);
+            hi[0] = fmaxf(hi[0], first_x[j]); hi[1] = fmaxf(hi[1], first_y[j]); hi[2] = fmaxf(hi[2], first_z[j]);
         }
     }
 #pragma unroll
@@ -508,10 +506,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
         if (k < n) {
-            float px_, py_, pz_;
-            fps_load_xyz(pts, (size_t)k, pstride, vec4, px_, py_, pz_);
             uint32_t q3[3];
-            fps_cell_coords(grid, px_ - lo[0], py_ - lo[1], pz_ - lo[2], q3);
+            fps_cell_coords(grid, first_x[j] - lo[0], first_y[j] - lo[1], first_z[j] - lo[2], q3);
             const uint32_t mc = use_lut ? (uint32_t)cell_lut[0][q3[0]] | cell_lut[1][q3[1]] | cell_lut[2][q3[2]]
                                         : fps_cell_key(grid, q3[0], q3[1], q3[2]);
             atomicAdd(&hist[mc], 1u);
@@ -559,10 +555,19 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
     // groups are ranked by box size (half the surface area) and dealt in serpentine order: wave w gets ranks w,
     // 2 NW - 1 - w, 2 NW + w, ... -- every wave one large, one small and two medium groups, and neighbours in space
     // (adjacent ranks are mostly adjacent regions) on different waves and SIMDs. Costs one extra pass over the points.
-    constexpr bool DEALT = MODE == 3;
+    // Since the second session of round 3 the default is the plain round-robin deal in key order again (group g of wave w =
+    // sorted group g NW + w): the ranking needs a pass of its own over the points, fetched by sorted index -- 26k cycles per
+    // cloud alone, 25 us of a 750 us launch with 160 clouds in flight -- and never bought more than it cost (737 vs 729 us
+    // when it was introduced); the slice boxes come out of the registers of step 3 instead. 752 -> 720 us per 160 clouds.
+#ifndef FPS_ROUND_ROBIN
+#define FPS_ROUND_ROBIN 1                       // MODE 3 deals its groups round-robin in key order; 0 (A/B builds): by box size, below
+#endif
+    constexpr bool MAPPED = MODE == 3;                     // groups owned through the dq[] map (else: a wave's contiguous share)
+    constexpr bool DEALT = MODE == 3 && !FPS_ROUND_ROBIN;  // ... and the map comes from the box-size ranking
+    constexpr bool SLICES_IN_STEP3 = MAPPED && !DEALT;     // slice boxes from the registers of step 3 (no pass of their own)
     int dq[G];                                             // sorted group of this wave's group g (wave-uniform)
 #pragma unroll
-    for (int g = 0; g < G; ++g) dq[g] = wave * G + g;
+    for (int g = 0; g < G; ++g) dq[g] = (MAPPED && !DEALT) ? g * NW + wave : wave * G + g;
     // Extent of sorted group q (the wave's contiguous share, before dealing) and, on request, the boxes of its S slices
     // (slice i = sorted positions [(q S + i) 64, + 64): a compact sub-cell; set abstraction tests them one by one)
     auto group_extent = [&](int q, float (&d)[3]) {
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int a = 0; a < 3; ++a) d[a] = reduced ? ghi3[a] - glo3[a] : fps_shfl_max(ghi3[a]) - fps_shfl_min(glo3[a]);
     };
-    if constexpr (!DEALT) {
+    if constexpr (!DEALT && !SLICES_IN_STEP3) {
         if (slice_box != nullptr && S > 1) {
 #pragma unroll
             for (int g = 0; g < G; ++g) { float d[3]; group_extent(wave * G + g, d); }
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         return q;
     };
     auto slot_pos = [&](int jj, int ln) -> int {           // position in sbuf of lane ln's slot jj (this wave); jj a constant
-        if constexpr (DEALT) return (deal(jj / S) * S + (jj % S)) * 64 + ln;
+        if constexpr (MAPPED) return (deal(jj / S) * S + (jj % S)) * 64 + ln;
         else return wave * 64 * P + jj * 64 + ln;
     };
     auto slot_pos_g = [&](int g, int jj, int ln) -> int {  // the same for a slot of group g (a constant) given at run time
@@ -702,6 +707,33 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 group_pts[(size_t)deal(g) * (64 * S) + run[i] * 64 + lane] =
                     make_float4(ok ? x : 3.0e38f, ok ? y : 3.0e38f, ok ? z : 3.0e38f,
                                 __uint_as_float(ok ? fps_tk1024_inv(tkg[i]) : 0xFFFFFFFFu));
+            }
+        }
+        if constexpr (SLICES_IN_STEP3 && S > 1) {
+            if (slice_box != nullptr) {                     // wave-uniform: a lane holds one point of each of the S slices (runs)
+#pragma unroll
+                for (int r = 0; r < S; ++r) {
+                    float c3[3] = {vec_get<P>(px, g * S), vec_get<P>(py, g * S), vec_get<P>(pz, g * S)};
+                    bool ok = tkg[0] != 0xFFFFu;
+#pragma unroll
+                    for (int i = 1; i < S; ++i) {
+                        const bool mine = run[i] == (uint32_t)r;
+                        c3[0] = mine ? vec_get<P>(px, g * S + i) : c3[0];
+                        c3[1] = mine ? vec_get<P>(py, g * S + i) : c3[1];
+                        c3[2] = mine ? vec_get<P>(pz, g * S + i) : c3[2];
+                        ok = mine ? tkg[i] != 0xFFFFu : ok;
+                    }
+                    float sb[6];
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        sb[a] = fps_shfl_min(ok ? c3[a] : 3.0e38f);
+                        sb[3 + a] = fps_shfl_max(ok ? c3[a] : -3.0e38f);
+                    }
+                    if (lane < 8)
+                        slice_box[(size_t)(deal(g) * S + r) * 8 + lane] =
+                            lane == 0 ? sb[0] : lane == 1 ? sb[1] : lane == 2 ? sb[2] : lane == 3 ? sb[3]
+                            : lane == 4 ? sb[4] : lane == 5 ? sb[5] : 0.f;
+                }
             }
         }
         float box[6];
