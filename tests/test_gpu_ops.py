@@ -50,6 +50,31 @@ def test_fps_bit_exact(kind, b, n, m):
     assert torch.equal(got, want), 'first mismatch at {}'.format((got != want).nonzero()[:3].tolist())
 
 
+def test_fps_reproduces_the_reference_numpy_sampler(golden_dir):
+    """The rows the reference's own numpy sampler picks (tests/golden/fps_reference.npz, written by
+    tests/golden/make_fps_golden.py from deepclr/data/transforms/transforms.py:47-59) on tie-free clouds, against both
+    sampler entry points of the library (level 1 and the fused path's `fps_clouds`, single clouds and all in one batch)."""
+    import os
+    g = np.load(os.path.join(golden_dir, 'fps_reference.npz'))
+    names = sorted({k.split('/')[0] for k in g.files})
+    checked = 0
+    for name in names:
+        pts, picks, m = g[name + '/points'], g[name + '/picks'], int(g[name + '/m'])
+        if m >= len(pts):
+            continue
+        x = torch.from_numpy(pts)[None].to(DEV)
+        assert np.array_equal(ops.furthest_point_sample(x, m).cpu().numpy()[0], picks), name
+        assert np.array_equal(ops.fps_clouds(x, m).cpu().numpy()[0], picks), name
+        checked += 1
+    assert checked >= 5
+    same = [n for n in names if g[n + '/points'].shape[0] == 2048 and int(g[n + '/m']) == 512]
+    if len(same) > 1:                                              # several reference clouds in one launch
+        x = torch.from_numpy(np.stack([g[n + '/points'] for n in same])).to(DEV)
+        got = ops.fps_clouds(x, 512).cpu().numpy()
+        for row, n in zip(got, same):
+            assert np.array_equal(row, g[n + '/picks']), n
+
+
 def test_fps_level1_large_cloud_and_temp_side_effect():
     """Level 1 through the C symbol: n > 65536 takes the global-temp kernel, 16385..65536 the workspace kernel on a
     stream-ordered scratch allocation, smaller clouds the register kernel; temp must hold the running minima over the
