@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow_kernel(int pairs, in
             const float wb0 = w1a[(2 * lane + 1) * 3 + 0], wb1 = w1a[(2 * lane + 1) * 3 + 1],
                         wb2 = w1a[(2 * lane + 1) * 3 + 2];
             const float base0 = ptv.x + bv.x, base1 = ptv.y + bv.y;
-            const int my_nb = lane < k ? knn_idx[gp * k + lane] : 0;
+            // an unfilled search slot (-1) reads row 0 and is masked like a neighbour beyond the radius (see flow16.hip)
+            const int raw_nb = lane < k ? knn_idx[gp * k + lane] : 0;
+            const uint32_t filled = (uint32_t)__ballot(lane < k && raw_nb >= 0);
+            const int my_nb = raw_nb < 0 ? 0 : raw_nb;
             const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
 #pragma unroll 4
             for (int s = 0; s < k; ++s) {
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow_kernel(int pairs, in
                 const float norm = sqrtf(dx * dx + dy * dy + dz * dz);
                 if (!(radius > 0.f) || norm < radius) bits |= 1u << s;
             }
+            bits &= filled;
             s_done = k;
         }
         for (int s = s_done; s < 4 * T; ++s) {                          // padding rows (k % 4 != 0, or no point)

@@ -130,12 +130,16 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
             const float *trow = f_rows + gp * DCLR_F_STRIDE;             // template clouds come first
             const float tx = trow[64], ty = trow[65], tz = trow[66];
             const size_t src0 = (pairs + pair) * (size_t)npoint;         // first row of the source cloud
-            const int my_nb = (ABL & 1) ? (lane & 15) : (lane < k ? knn_idx[gp * k + lane] : 0);
+            // a slot the search left unfilled (-1: fewer than k candidates within the 1e10 start distance of the slots, or
+            // NaN coordinates; upstream fails at its .view(2, G, k) there) reads row 0 and is masked like a neighbour
+            // beyond the radius: no address ever leaves the source cloud
+            const int raw_nb = (ABL & 1) ? (lane & 15) : (lane < k ? knn_idx[gp * k + lane] : 0);
+            const int my_nb = raw_nb < 0 ? 0 : raw_nb;
             const float4 nbp = (ABL & 1) ? make_float4(tx + lane, ty, tz, 0.f)
                                          : *reinterpret_cast<const float4 *>(f_rows + (src0 + my_nb) * DCLR_F_STRIDE + 64);
             const float my_dx = nbp.x - tx, my_dy = nbp.y - ty, my_dz = nbp.z - tz;
             const float norm = sqrtf(my_dx * my_dx + my_dy * my_dy + my_dz * my_dz);
-            bits = (uint32_t)__ballot(lane < k && (!(radius > 0.f) || norm < radius));
+            bits = (uint32_t)__ballot(lane < k && raw_nb >= 0 && (!(radius > 0.f) || norm < radius));
             constexpr int KMAX = 4 * T;
             float2 psv[KMAX];
             const float *psrow = ps + pair * (size_t)npoint * F16_C + 2 * lane;

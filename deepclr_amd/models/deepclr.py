@@ -154,15 +154,17 @@ class MotionEmbeddingBase(nn.Module):
             }
         return self._cache.get(flat_parameters(self), build)
 
-    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int) -> torch.Tensor:
-        """rows F of [templates..., sources...] -> rows E (pairs*npoint, 264)."""
+    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int, precision: Optional[str] = None) -> torch.Tensor:
+        """rows F of [templates..., sources...] -> rows E (pairs*npoint, 264). precision: matrix path of this call
+        ('f16x2' / 'f32'); None = ops.PRECISION."""
+        precision = precision or ops.PRECISION
         p = self._packed()
         half = pairs * npoint
         pt = ops.linear(f_rows[:half], p['wt'], None, 128, FEAT, relu=False)
         ps = ops.linear(f_rows[half:], p['ws'], None, 128, FEAT, relu=False)
 
         def embed(idx):
-            if ops.PRECISION == 'f16x2':
+            if precision == 'f16x2':
                 return ops.flow_embedding_fused_f16(f_rows, idx, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'],
                                                     p['w3h'], p['b3'], self._radius)
             return ops.flow_embedding_fused(f_rows, idx, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'],
@@ -202,8 +204,8 @@ class MotionEmbedding(DeepCLRModule):
     def output_dim(self) -> int:
         return self._embedding.output_dim()
 
-    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int) -> torch.Tensor:
-        return self._embedding.forward_rows(f_rows, pairs, npoint)
+    def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int, precision: Optional[str] = None) -> torch.Tensor:
+        return self._embedding.forward_rows(f_rows, pairs, npoint, precision)
 
     def forward(self, clouds: torch.Tensor) -> torch.Tensor:
         half = clouds.shape[0] // 2
@@ -272,20 +274,21 @@ class OutputSimple(DeepCLRModule):
             return layers
         return self._cache16.get(flat_parameters(self.conv), build)
 
-    def _fusable(self, layers, rows: int, pairs: int) -> bool:
+    def _fusable(self, layers, rows: int, pairs: int, precision: Optional[str] = None) -> bool:
         """The one-launch conv chain needs 32-row tiles inside one pair and hidden widths <= 512. Its grid is
         rows / 32 workgroups, one per CU. On the f32 matrix path, below half the chip (single pairs, the reference's
         own batch size) the per-layer kernels, whose grids also split the output columns, finish sooner (84 vs
         142 us at one pair); the split-fp16 chain (65 us) is used at every batch size, which also keeps the
         result of a pair independent of the batch it travels in."""
-        return ((rows >= 4096 or ops.PRECISION == 'f16x2') and rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
+        return ((rows >= 4096 or (precision or ops.PRECISION) == 'f16x2') and rows % 32 == 0 and (rows // pairs) % 32 == 0 and len(layers) <= 8
                 and all(n % 32 == 0 for _, _, n, _ in layers) and all(kp <= 512 for _, _, _, kp in layers)
                 and all(n <= 512 for _, _, n, _ in layers[:-1]))
 
-    def forward_rows(self, e_rows: torch.Tensor, pairs: int) -> torch.Tensor:
+    def forward_rows(self, e_rows: torch.Tensor, pairs: int, precision: Optional[str] = None) -> torch.Tensor:
+        precision = precision or ops.PRECISION
         layers = self._packed()
-        if self._fusable(layers, e_rows.shape[0], pairs) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
-            if ops.PRECISION == 'f16x2':
+        if self._fusable(layers, e_rows.shape[0], pairs, precision) and os.environ.get('DCLR_HEAD_FUSED', '1') != '0':
+            if precision == 'f16x2':
                 g = ops.head_conv_fused_f16(e_rows, ops.E_STRIDE, self._packed_f16(), pairs)
             else:
                 g = ops.head_conv_fused(e_rows, layers, pairs)               # conv chain + max over points
@@ -567,7 +570,8 @@ class DeepCLR(BaseModel):
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
-        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and (ops.CHECK_RANGE == 'always' or self._range_unchecked()):
+        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and not self.training \
+                and (ops.CHECK_RANGE == 'always' or self._range_unchecked()):
             return self._merge_rows_checked(f_rows, pairs, out)
         plan = self._merge_plan(f_rows, pairs)
         if plan is not None:
@@ -591,14 +595,17 @@ class DeepCLR(BaseModel):
         range (the split path clamps at +-65504 and would return wrong poses silently). Runs on the first forward after
         the weights changed (ops.CHECK_RANGE = 'first', the default: two host syncs, once) or on every forward ('always')."""
         flow, head = self._merge_layers[0], self._merge_layers[1]
-        e16 = flow.forward_rows(f_rows, pairs, self.npoint)
-        y16 = head.forward_rows(e16, pairs)
-        ops.PRECISION = 'f32'
-        try:
-            e32 = flow.forward_rows(f_rows, pairs, self.npoint)
-            y32 = head.forward_rows(e32, pairs)
-        finally:
-            ops.PRECISION = 'f16x2'
+        k = getattr(getattr(flow, '_embedding', None), '_k', 0)
+        if k > 0 and bool((ops.knn_rows(f_rows, pairs, self.npoint, k) < 0).any()):
+            # upstream fails here too: torch_cluster.knn returns fewer than k neighbours for such a query and
+            # KnnGrouping's .view(2, G, k) raises (reference deepclr.py:164-167). The unchecked forwards mask the
+            # unfilled slots instead (csrc/flow16.hip) -- memory-safe, but not a result upstream would have produced.
+            raise RuntimeError("kNN grouping: a template point has fewer than k = {} source points within the search's "
+                               "start distance (1e5 m), or non-finite coordinates reached the flow embedding".format(k))
+        e16 = flow.forward_rows(f_rows, pairs, self.npoint, 'f16x2')
+        y16 = head.forward_rows(e16, pairs, 'f16x2')
+        e32 = flow.forward_rows(f_rows, pairs, self.npoint, 'f32')
+        y32 = head.forward_rows(e32, pairs, 'f32')
         peak = max(float(f_rows.abs().max()), float(e32.abs().max()))
         err = float((y16 - y32).abs().max())
         if not (err <= 1e-4 * max(1.0, float(y32.abs().max()))) or not peak < ops.F16_MAX:

@@ -36,6 +36,10 @@ PRECISION = os.environ.get('DCLR_PRECISION', 'f16x2')
 SLICE_BOXES = os.environ.get('DCLR_SLICE_BOXES', '1') != '0'    # A/B: 0 = set abstraction tests whole 256-point groups only
 CHECK_RANGE = {'1': 'always', '0': 'never'}.get(os.environ.get('DCLR_CHECK_RANGE', 'first'),
                                                 os.environ.get('DCLR_CHECK_RANGE', 'first'))
+if CHECK_RANGE not in ('first', 'always', 'never'):
+    raise RuntimeError("DCLR_CHECK_RANGE must be one of first, always, never, 1, 0 (got '{}')".format(CHECK_RANGE))
+if PRECISION not in ('f16x2', 'f32'):
+    raise RuntimeError("DCLR_PRECISION must be f16x2 or f32 (got '{}')".format(PRECISION))
 F16_MAX = 65504.0
 
 

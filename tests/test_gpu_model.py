@@ -975,3 +975,45 @@ def test_fused_set_abstraction_random_configurations(c, n, npoint, r0, r1, ns0, 
     against the oracle -- counts exact, features within tolerance, group path identical to the exhaustive sweep."""
     radii, nsamples = ((r0,), (ns0,)) if scales == 1 else ((r0, r1), (ns0, ns1))
     _check_set_abstraction(c, n, min(npoint, n), radii, nsamples, expect_cap=False)
+
+
+def test_unfilled_knn_slots_raise_on_the_checked_forward_and_are_masked_after(monkeypatch):
+    """torch-cluster's k slots start at distance 1e10 / index -1: a template point with fewer than k source points within
+    1e5 m (or NaN coordinates in the source cloud) gets -1 entries. Upstream fails there (KnnGrouping's .view(2, G, k),
+    reference deepclr.py:164-167). Here the checked forward -- the default on first use -- raises; the unchecked fused
+    path must stay inside its buffers (pair 0's source rows start the `ps` buffer: an index of -1 would read in front of
+    it) and treats the slot as a masked neighbour: the result equals that of the same lists with every -1 replaced by a
+    far, radius-masked source row."""
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=4))
+    pairs, npoint, k = 2, model.npoint, 20
+    rng = np.random.default_rng(8)
+    f = np.zeros((2 * pairs * npoint, ops.F_STRIDE), dtype=np.float32)
+    f[:, :64] = np.abs(rng.normal(size=(len(f), 64)))
+    f[:, 64:67] = rng.normal(scale=3.0, size=(len(f), 3))
+    src = f[pairs * npoint:].reshape(pairs, npoint, ops.F_STRIDE)
+    src[0, 12:, 64] += 3.0e5                     # pair 0: only 12 source points within reach -> 8 unfilled slots per query
+    src[1, 5:9, 64:67] = np.nan                  # pair 1: four source rows without a position, never taken
+    src[1, 40:, 65] -= 2.5e5                     # ... and 36 reachable ones left: slots 0..19 filled, no -1
+    src[1, 5:9, 64:67] = np.nan
+    f_rows = torch.from_numpy(f).to(DEV)
+    idx = ops.knn_rows(f_rows, pairs, npoint, k)
+    assert bool((idx[0, :, 12:] == -1).all()) and bool((idx[0, :, :12] >= 0).all()) and bool((idx[1] >= 0).all())
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match='kNN grouping'):
+            model.merge_rows(f_rows, pairs)
+        monkeypatch.setattr(ops, 'CHECK_RANGE', 'never')
+        y = model.merge_rows(f_rows, pairs)                                  # dclr_merge_forward, split-f16
+        flow = model._merge_layers[0]._embedding
+        p = flow._packed()
+        pt = ops.linear(f_rows[:pairs * npoint], p['wt'], None, 128, 64, relu=False)
+        ps = ops.linear(f_rows[pairs * npoint:], p['ws'], None, 128, 64, relu=False)
+        far = idx.clone()
+        far[far < 0] = npoint - 1                                            # a source row 3e5 m away: beyond the radius
+        for fn, w2, w3 in ((ops.flow_embedding_fused_f16, 'w2h', 'w3h'), (ops.flow_embedding_fused, 'w2p', 'w3p')):
+            args = (pt, ps, p['w1a'], p['b1'], p[w2], p['b2'], p[w3], p['b3'], flow._radius)
+            got, want = fn(f_rows, idx, *args), fn(f_rows, far, *args)
+            assert torch.isfinite(got[:pairs * npoint // 2]).all() and torch.equal(got, want)
+        e = ops.flow_embedding_fused_f16(f_rows, far, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'], p['w3h'], p['b3'], flow._radius)
+        y_far = model._merge_layers[1].forward_rows(e, pairs)
+    assert torch.isfinite(y[0]).all() and torch.equal(y[0], y_far[0])
