@@ -827,7 +827,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
 #pragma unroll
         for (int g = 0; g < G; ++g) { cur_wl[g] = 0; cur_jj[g] = g * S; cur_b[g] = 0xFFFFFFFFu; }
 #ifdef FPS_DEBUG
-        unsigned long long mu = 0, mb = 0, mc = 0, mt = 0, mg = 0, mr = 0, mg_prev = 0, mr_prev = 0;
+        unsigned long long mu = 0, mb = 0, mc = 0, mt = 0, mg = 0, mr = 0, mg_prev = 0, mr_prev = 0, ml1 = 0, ml2 = 0, ml3 = 0;
 #endif
         for (int r = 0;;) {                                               // r: samples picked so far
 #ifdef FPS_DEBUG
@@ -1003,6 +1003,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                     // reduction's cross-lane steps (one straight run of instructions; a rejected candidate's mask is dropped)
                     reach[j] = box_test(wid[j]);
                 }
+#ifdef FPS_DEBUG
+                unsigned long long l1_; FPS_STAMP(l1_); ml1 += l1_ - q2;
+#endif
                 if (tie) {
                     // two entries share a value (duplicate points, lattices, an exhausted cloud): again, by (value, key).
                     // Kept out of the loop above so that the usual round is one straight run of instructions in which the
@@ -1035,6 +1038,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 const uint32_t dji = __float_as_uint(dclr_sqdist(xj, yj, zj, xi, yi, zi));
                 const bool pair_bad = lj < J && li < lj && !(vj > ui && dji >= vj);
                 const unsigned long long bad = __ballot(pair_bad);         // bits 8 j .. 8 j + 7: candidate j fails a test
+#ifdef FPS_DEBUG
+                unsigned long long l2_; FPS_STAMP(l2_); ml2 += l2_ - l1_;
+#endif
                 // candidate j joins iff every earlier one did; the level-1 contract (temp = minima over the first m - 1
                 // samples) gives the final sample a round of its own
                 int cnt = 1;
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                 unsigned long long am[J];
 #pragma unroll
                 for (int j = 0; j < J; ++j) am[j] = j < cnt ? reach[j] : 0ull;
-#ifdef FPS_DEBUG
+#ifdef FPS_DEBUG_MARKS                        // (a global read-modify-write inside the leader: off when the leader is being timed)
                 if (blockIdx.x == 0) {
                     unsigned long long all = 0;
 #pragma unroll
@@ -1064,6 +1070,9 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
                     rb_m[lj] = om;
                     if (lj < cnt) picked[r + lj] = kj;
                 }
+#ifdef FPS_DEBUG
+                unsigned long long l3_; FPS_STAMP(l3_); ml3 += l3_ - l2_;
+#endif
             }
             __syncthreads();
             sr += 1;
@@ -1082,7 +1091,8 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         if (lane == 0 && blockIdx.x == 0) {
             fps_dbg[11] = (unsigned long long)sr;
             if (wave == 3) { fps_dbg[12] = mu; fps_dbg[13] = mg; fps_dbg[14] = mb; fps_dbg[15] = mc; fps_dbg[10] = mt; fps_dbg[7] = mr; }
-            if (wave == 0) { fps_dbg[1] = mu; fps_dbg[2] = mb; fps_dbg[3] = mc; fps_dbg[5] = mt; fps_dbg[6] = mg; fps_dbg[8] = mr; }
+            if (wave == 0) { fps_dbg[1] = mu; fps_dbg[2] = mb; fps_dbg[3] = mc; fps_dbg[5] = mt; fps_dbg[6] = mg; fps_dbg[8] = mr;
+                             fps_dbg[0] = ml1; fps_dbg[4] = ml2; fps_dbg[9] = ml3; }   // leader: table + J maxima + box tests | pair tests | publish
         }
 #endif
     } else

@@ -6,6 +6,10 @@
 // every operand split into f16 hi/lo halves, three instructions per product, f32 accumulation.
 #include "mma16f.h"
 
+#ifndef H16_ABL
+#define H16_ABL 0                // timing probes of scratch/head_abl.sh only; the product library is built with 0
+#endif
+
 namespace {
 
 // ---- weight packing ------------------------------------------------------------------------------
@@ -68,18 +72,31 @@ __device__ __forceinline__ void head16_panel(dclr_f32x16 (&acc)[2][MT], dclr_f32
     // prefetch back into load-wait-use, see mma.h.)
     dclr_h8 wh[4][NT], wl[4][NT];
     auto fetch = [&](int g, dclr_h8 (&h)[NT], dclr_h8 (&l)[NT]) {
+#if H16_ABL & 1                  // timing probe: every step re-reads the first fragment (no stream from L2)
+        g = 0;
+#endif
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
+#if H16_ABL & 2                  // timing probe: no weight loads at all
+            h[u] = __builtin_bit_cast(dclr_h8, make_float4((float)g, 1.f, 2.f, (float)u));
+            l[u] = h[u];
+#else
             h[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)g * 64);
             l[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)g * 64);
+#endif
         }
     };
     auto step = [&](int g, const dclr_h8 (&h)[NT], const dclr_h8 (&l)[NT]) {
         dclr_h8 ah[MT], al[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
+#if H16_ABL & 4                  // timing probe: no activation reads from LDS
+            ah[t] = __builtin_bit_cast(dclr_h8, make_float4((float)g, 1.f, 2.f, (float)t));
+            al[t] = ah[t];
+#else
             ah[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g);
             al[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g + 16);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < NT; ++u)

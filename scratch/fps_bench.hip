@@ -46,6 +46,9 @@ int main(int argc, char **argv) {
                    dbg[11], (double)(m - 1) / dbg[11], (double)dbg[12] / dbg[11], (double)dbg[14] / dbg[11], (double)dbg[15] / dbg[11], dbg[10], dbg[13],
                    (double)dbg[1] / dbg[11], (double)dbg[2] / dbg[11], (double)dbg[3] / dbg[11], dbg[5], dbg[6]);
         if (!getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE") && dbg[11])
+            printf("   leader per round (cycles): table read + J maxima + box tests %.0f | pair tests %.0f | accept + publish %.0f\n",
+                   (double)dbg[0] / dbg[11], (double)dbg[4] / dbg[11], (double)dbg[9] / dbg[11]);
+        if (!getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE") && dbg[11])
             printf("   entries rewritten: wave 3 %llu of %llu group updates, wave 0 %llu of %llu\n", dbg[7], dbg[13], dbg[8], dbg[6]);
         if (rep == 2 && !getenv("DCLR_FPS_WAVECAND") && !getenv("DCLR_FPS_SINGLE")) {
             unsigned int grp[64];
