@@ -6,6 +6,11 @@
 // every operand split into f16 hi/lo halves, three instructions per product, f32 accumulation.
 #include "mma16f.h"
 
+#ifndef H16_PIPE
+#define H16_PIPE 3               // 3 (default since round 4): the activation fragments of step g + 1 are read while the MFMAs of
+                                 // step g run, and a step's loads / reads are dealt between its MFMAs (518 -> 496 us per 80 pairs);
+                                 // 1 = the read-ahead alone (515); 0 = round 3's loop (loads and reads in front of the MFMAs)
+#endif
 #ifndef H16_ABL
 #define H16_ABL 0                // timing probes of scratch/head_abl.sh only; the product library is built with 0
 #endif
@@ -86,6 +91,63 @@ __device__ __forceinline__ void head16_panel(dclr_f32x16 (&acc)[2][MT], dclr_f32
 #endif
         }
     };
+#if H16_PIPE
+    // (H16_PIPE) the activation fragments of step g + 1 are read from LDS while the MFMAs of step g run (two register sets),
+    // and the step's loads and reads are dealt between its MFMAs instead of standing in front of them
+    dclr_h8 ah2[2][MT], al2[2][MT];
+    auto read_act = [&](int g, dclr_h8 (&h)[MT], dclr_h8 (&l)[MT]) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            h[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g);
+            l[t] = dclr_lds_h8(a_lane + t * tile_bytes + 64 * g + 16);
+        }
+    };
+    auto mfmas = [&](const dclr_h8 (&h)[NT], const dclr_h8 (&l)[NT], const dclr_h8 (&xh)[MT], const dclr_h8 (&xl)[MT]) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc[u][t] = LAST ? dclr_mfma32(xh[t], h[u], acc[u][t]) : dclr_mfma32(h[u], xh[t], acc[u][t]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc2[u][t] = LAST ? dclr_mfma32(xh[t], l[u], acc2[u][t]) : dclr_mfma32(l[u], xh[t], acc2[u][t]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                acc2[u][t] = LAST ? dclr_mfma32(xl[t], h[u], acc2[u][t]) : dclr_mfma32(h[u], xl[t], acc2[u][t]);
+    };
+    fetch(0, wh[0], wl[0]);
+    fetch(kg > 1 ? 1 : 0, wh[1], wl[1]);
+    fetch(kg > 2 ? 2 : 0, wh[2], wl[2]);
+    read_act(0, ah2[0], al2[0]);
+    for (int g = 0; g < kg; g += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (g + i < kg) {                                          // wave-uniform
+                const int ahead = g + i + 3 < kg ? g + i + 3 : kg - 1;  // clamped: the load stays unconditional
+                const int nxt = g + i + 1 < kg ? g + i + 1 : kg - 1;
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(ahead, wh[(i + 3) & 3], wl[(i + 3) & 3]);
+                read_act(nxt, ah2[(i + 1) & 1], al2[(i + 1) & 1]);
+                mfmas(wh[i], wl[i], ah2[i & 1], al2[i & 1]);
+#if H16_PIPE & 2
+                // deal the 2 NT loads and 2 MT reads between the 3 NT MT MFMAs
+#pragma unroll
+                for (int q = 0; q < 2 * NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, (3 * NT * MT) / (2 * NT + 1), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (2 * MT + 2 * NT - 1) / (2 * NT), 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT * MT, 0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#else
     auto step = [&](int g, const dclr_h8 (&h)[NT], const dclr_h8 (&l)[NT]) {
         dclr_h8 ah[MT], al[MT];
 #pragma unroll
@@ -129,6 +191,7 @@ __device__ __forceinline__ void head16_panel(dclr_f32x16 (&acc)[2][MT], dclr_f32
             }
         }
     }
+#endif
 }
 
 template <int MT>
