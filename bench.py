@@ -152,7 +152,7 @@ class LaunchTimer:
 
     POOL = 256                       # events created up front: creation is host time inside a short timed window
 
-    RAW_POOL = 48                    # dclr_merge_forward calls bracketed before the pool has to grow inside the window
+    RAW_POOL = 64                    # dclr_merge_forward / dclr_cloud_forward calls bracketed before the pool has to grow inside the window
 
     def __init__(self, sample_every=None, raw_pool=None):
         raw_pool = self.RAW_POOL if raw_pool is None else raw_pool
@@ -160,6 +160,8 @@ class LaunchTimer:
         self.raw = []
         self.calls = {}
         self._hip = None
+        from deepclr_amd import lib as _lib
+        self._stream_ptr = _lib.stream_ptr
         self.main_stream = torch.cuda.current_stream().cuda_stream
         if sample_every is not None:
             self.SAMPLE_EVERY = sample_every
@@ -223,7 +225,7 @@ class LaunchTimer:
             return None
         start = self._event()
         start.record()
-        return (name, start, torch.cuda.current_stream().cuda_stream == self.main_stream)
+        return (name, start, self._stream_ptr() == self.main_stream)
 
     def end(self, token):
         if token is None:
@@ -250,8 +252,25 @@ class LaunchTimer:
         arr = self._raw_pool.pop() if self._raw_pool else self._new_raw()
         if arr is None:
             return None
-        on_main = torch.cuda.current_stream().cuda_stream == self.main_stream
+        on_main = self._stream_ptr() == self.main_stream
         self.raw.append((arr, names, on_main))
+        return arr
+
+    def cloud_events(self, clouds, n):
+        """Raw HIP events for the two per-cloud stages of one dclr_cloud_forward call (start, after sampling, after set
+        abstraction), recorded by the library on the launch stream; the stage-1 events of the same call come from
+        merge_events(..., stages=1)."""
+        names = ['fps_clouds[%dx%d]' % (clouds, n), 'sa_msg_fused[%dx%d]' % (clouds, n)]
+        for nm in names:
+            self.calls[nm] = self.calls.get(nm, 0) + 1
+        if not self._sampled('cloud_forward'):
+            return None
+        if self._hip is None:
+            self._hip = self._load_hip()
+        arr = self._raw_pool.pop() if self._raw_pool else self._new_raw()
+        if arr is None:
+            return None
+        self.raw.append((arr, names, self._stream_ptr() == self.main_stream))
         return arr
 
     def summary(self):

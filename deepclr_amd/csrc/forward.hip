@@ -67,3 +67,36 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     }
     return DCLR_OK;
 }
+
+// The per-cloud stages of one launch group behind a single entry point (reference call order: DeepCLR.cloud_features ->
+// SetAbstraction, /root/reference/deepclr/models/deepclr.py:510-521,86-93; then the grouping half of MotionEmbedding,
+// deepclr.py:149-171, which needs nothing but the rows just written).
+extern "C" int dclr_cloud_forward(const DclrCloudArgs *a, void *const *events, void *const *merge_events,
+                                  dclr_stream_t stream) {
+    DCLR_REQUIRE(a != nullptr);
+    DCLR_REQUIRE(a->b > 0 && a->n > 0 && a->c >= 3 && a->npoint > 0 && a->n_scales >= 1 && a->n_scales <= DCLR_CLOUD_MAX_SCALES);
+    DCLR_REQUIRE(a->clouds && a->fps_idx && a->group_pts && a->group_box && a->f_rows);
+    hipStream_t st = (hipStream_t)stream;
+    int slot = 0;
+    auto mark = [&]() {
+        if (events && events[slot]) (void)hipEventRecord((hipEvent_t)events[slot], st);
+        ++slot;
+    };
+    mark();
+    int rc = dclr_fps_clouds_grouped_batched(a->b, a->n, a->c, a->npoint, a->clouds, a->pairs_per_batch, a->n_batches,
+                                             a->batch_stride, a->fps_idx, a->group_pts, a->group_box, a->slice_box,
+                                             a->workspace, a->workspace_bytes, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    rc = dclr_sa_msg_fused_batched(a->f16, a->b, a->n, a->c, a->npoint, a->clouds, a->pairs_per_batch, a->n_batches,
+                                   a->batch_stride, a->fps_idx, a->n_scales, a->radii, a->nsamples, a->mlp, a->f_rows, nullptr,
+                                   a->group_pts, a->group_box, a->slice_box, stream);
+    if (rc != DCLR_OK) return rc;
+    mark();
+    if (a->merge == nullptr) return DCLR_OK;
+    DclrMergeArgs m = *a->merge;
+    DCLR_REQUIRE(2 * m.pairs == a->b && m.npoint == a->npoint);
+    m.f_rows = a->f_rows;
+    m.stages = 1;
+    return dclr_merge_forward(&m, merge_events, stream);
+}

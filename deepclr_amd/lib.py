@@ -50,6 +50,7 @@ SIGNATURES = {
     'dclr_head_conv_fused_f16': [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     'dclr_flow_embedding_fused_f16': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_merge_forward': [_p, _p, _p],
+    'dclr_cloud_forward': [_p, _p, _p, _p],
     'dclr_prepare_cloud_blocks': [_i, _i, _i],
     'dclr_prepare_cloud': [_i, _i, _p, _i, _i, _f, _f, _i, _p, _p, _p, _p],
 }
@@ -69,6 +70,20 @@ class MergeArgs(ctypes.Structure):
         ('head_w', _p * MERGE_MAX_LAYERS), ('head_b', _p * MERGE_MAX_LAYERS),
         ('fc_w', _p * MERGE_MAX_FC), ('fc_b', _p * MERGE_MAX_FC),
         ('pt', _p), ('ps', _p), ('knn_idx', _p), ('e_rows', _p), ('colmax', _p), ('fc_tmp', _p * 2), ('y', _p),
+    ]
+
+
+CLOUD_MAX_SCALES, CLOUD_EVENTS = 4, 3
+
+
+class CloudArgs(ctypes.Structure):
+    """DclrCloudArgs (include/deepclr_amd.h)."""
+    _fields_ = [
+        ('b', _i), ('n', _i), ('c', _i), ('npoint', _i), ('pairs_per_batch', _i), ('n_batches', _i),
+        ('batch_stride', ctypes.c_longlong), ('f16', _i), ('n_scales', _i),
+        ('radii', _f * CLOUD_MAX_SCALES), ('nsamples', _i * CLOUD_MAX_SCALES), ('mlp', _p * CLOUD_MAX_SCALES),
+        ('clouds', _p), ('fps_idx', _p), ('group_pts', _p), ('group_box', _p), ('slice_box', _p),
+        ('workspace', _p), ('workspace_bytes', ctypes.c_longlong), ('f_rows', _p), ('merge', _p),
     ]
 
 
@@ -100,7 +115,19 @@ def check(code: int, what: str) -> None:
         raise RuntimeError("{} failed: {} (code {})".format(what, msg, code))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device. torch.cuda.current_stream() builds a Stream object and
+    resolves the device through several Python layers (~10 us per call; the pipelined runner asks several times per launch):
+    the raw accessors take ~0.3 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        try:
+            return _raw_stream(_raw_device())
+        except Exception:                         # no device (CPU-only unit tests): the public accessor says so properly
+            pass
     return torch.cuda.current_stream().cuda_stream
 
 

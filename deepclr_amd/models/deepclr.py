@@ -495,6 +495,95 @@ class _MergePlan:
         return y
 
 
+class _CloudPlan:
+    """Arguments + scratch of dclr_cloud_forward (sampling -> set abstraction -> layer-1 halves + kNN in ONE foreign call)
+    for one (device, stream, launch shape, matrix path). The sampler's index list and spatial groups are scratch of the
+    plan (reused by the next call on the same stream); the products -- rows F and the stage-1 buffers of the dense stages --
+    come out of a small ring whose slots are handed out again once their consumer has released them (_Prep.release)."""
+
+    RING = 3
+
+    def __init__(self, args, keep, versions, merge_plan: _MergePlan, shapes, device):
+        self.args, self._keep, self._versions, self._merge = args, keep, versions, merge_plan
+        self._shapes, self._device = shapes, device
+        self._ring, self._next = [], 0
+
+    def current(self) -> bool:
+        return self._versions == _MergePlan._version_key(self._keep['mods']) and self._merge.current()
+
+    @classmethod
+    def build(cls, sa, merge_plan: _MergePlan, device, per: int, nb: int, n: int, c: int):
+        layout = ops.fps_group_layout(n)
+        npoint, ns = sa.npoint, len(sa.radii)
+        b = 2 * per * nb
+        if layout is None or ns > lib.CLOUD_MAX_SCALES or (n > 16384 and npoint * 4 > 32 * 1024):
+            return None
+        ng, gs = layout
+        a = lib.CloudArgs()
+        a.b, a.n, a.c, a.npoint, a.pairs_per_batch, a.n_batches = b, n, c, npoint, per, nb
+        a.f16, a.n_scales = int(ops.PRECISION == 'f16x2'), ns
+        mlps = sa.packed_mlps()
+        for i in range(ns):
+            a.radii[i], a.nsamples[i], a.mlp[i] = float(sa.radii[i]), int(sa.nsamples[i]), mlps[i].data_ptr()
+        scratch = {'idx': torch.empty(b, npoint, dtype=torch.int32, device=device),
+                   'gpts': torch.empty(b, ng * gs, 4, device=device), 'gbox': torch.empty(b, ng, 8, device=device)}
+        if n <= 16384 and gs > 64 and ops.SLICE_BOXES:
+            scratch['sbox'] = torch.empty(b, ng * (gs // 64), 8, device=device)
+        need = lib.load().dclr_fps_workspace_bytes(b, n) if n > 16384 else 0
+        if need:
+            scratch['ws'] = torch.empty((need + 3) // 4, dtype=torch.int32, device=device)
+        a.fps_idx, a.group_pts, a.group_box = scratch['idx'].data_ptr(), scratch['gpts'].data_ptr(), scratch['gbox'].data_ptr()
+        a.slice_box, a.workspace, a.workspace_bytes = lib.ptr(scratch.get('sbox')), lib.ptr(scratch.get('ws')), need
+        a.merge = ctypes.addressof(merge_plan.args)
+        keep = {'mods': [sa], 'scratch': scratch, 'mlps': mlps}
+        k = merge_plan.args.k
+        shapes = ((b * npoint, ops.F_STRIDE), (per * nb * npoint, 128), (per * nb, npoint, k))
+        return cls(a, keep, _MergePlan._version_key(keep['mods']), merge_plan, shapes, device)
+
+    def _fresh(self):
+        rows_s, half_s, knn_s = self._shapes
+        return _Prep((torch.empty(half_s, device=self._device), torch.empty(half_s, device=self._device),
+                      torch.empty(knn_s, dtype=torch.int32, device=self._device), torch.empty(rows_s, device=self._device)))
+
+    def fill_ring(self) -> None:
+        """Allocate every slot of the ring now (released: free to hand out)."""
+        while len(self._ring) < self.RING:
+            slot = self._fresh()
+            slot.release()
+            self._ring.append(slot)
+
+    def _slot(self):
+        fresh = self._fresh
+        if len(self._ring) < self.RING:
+            out = fresh()
+            self._ring.append(out)
+            return out
+        old = self._ring[self._next]
+        if old.done is None:                            # never released by its consumer: leave it alone, take fresh memory
+            out = fresh()
+        else:
+            torch.cuda.current_stream().wait_event(old.done)
+            out = _Prep(tuple(old))
+        self._ring[self._next] = out
+        self._next = (self._next + 1) % self.RING
+        return out
+
+    def run(self, clouds: torch.Tensor, stride: int, events=None, merge_events=None):
+        """clouds: the first batch (2 per, n, c) of the launch, the others `stride` floats apart -> (rows F, prep)."""
+        a, m = self.args, self._merge.args
+        if clouds.shape != (2 * a.pairs_per_batch, a.n, a.c):
+            raise RuntimeError("clouds do not match the planned launch shape")
+        out = self._slot()
+        a.clouds, a.batch_stride, a.f_rows = lib.dev_f32(clouds, 'clouds').data_ptr(), stride, out[3].data_ptr()
+        saved = (m.pt, m.ps, m.knn_idx)
+        m.pt, m.ps, m.knn_idx = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
+        try:
+            lib.check(lib.load().dclr_cloud_forward(ctypes.byref(a), events, merge_events, lib.stream_ptr()), 'cloud_forward')
+        finally:
+            m.pt, m.ps, m.knn_idx = saved
+        return out[3], out
+
+
 # --------------------------------------------------------------------------------------------------
 class DeepCLR(BaseModel):
     """Set abstraction over all 2B clouds -> flow embedding per pair -> pose head."""
@@ -565,6 +654,59 @@ class DeepCLR(BaseModel):
         events = ops.TIMER.merge_events(pairs, self.npoint, plan.args.k, plan.args.n_fc, 1) if ops.TIMER is not None else None
         return plan.prep(f_rows, events)
 
+    def cloud_merge_prep(self, x: torch.Tensor, view=None):
+        """cloud_feature_rows + merge_prep behind ONE foreign call (dclr_cloud_forward): (2B, N, C) [x view] -> (rows F,
+        prep), or None where the one-call path does not apply (a second set-abstraction level, shapes without a grouped
+        sampler or a merge plan, the first -- range-checked -- forward after the weights changed): callers then take the
+        two methods one after the other. The pipelined runner's sampling chain: ~0.3 ms of host time per launch otherwise."""
+        sa = self._cloud_layers[0]
+        sa0 = getattr(sa, '_sa0', None)
+        if sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda or x.shape[0] % 2 \
+                or x.shape[2] != self._input_dim or not x.is_contiguous() or x.dtype != torch.float32 \
+                or os.environ.get('DCLR_CLOUD_FUSED', '1') == '0':
+            return None
+        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and (
+                ops.CHECK_RANGE == 'always' or self._range_unchecked() or sa0.range_unchecked()):
+            return None
+        per, nb, stride = view if view is not None else (x.shape[0] // 2, 1, 0)
+        plan = self._cloud_plan(sa0, x, per, nb)
+        if plan is None:
+            return None
+        events = merge_events = None
+        if ops.TIMER is not None:
+            events = ops.TIMER.cloud_events(2 * per * nb, x.shape[1])
+            merge_events = ops.TIMER.merge_events(per * nb, self.npoint, plan._merge.args.k, plan._merge.args.n_fc, 1)
+        return plan.run(x, stride, events, merge_events)
+
+    def _cloud_plan(self, sa0, x: torch.Tensor, per: int, nb: int):
+        key = ('cloud', x.device, per, nb, x.shape[1], ops.PRECISION, lib.stream_ptr())
+        plan = self._plans.get(key)
+        if plan is None or not plan.current():
+            merge_plan = self._merge_plan(x, per * nb)
+            if merge_plan is None:
+                return None
+            plan = _CloudPlan.build(sa0, merge_plan, x.device, per, nb, x.shape[1], x.shape[2])
+            if plan is None:
+                return None
+            self._plans[key] = plan
+        return plan
+
+    def plan_cloud_forward(self, x: torch.Tensor, view=None) -> bool:
+        """Build now, for the CURRENT stream, what cloud_merge_prep(x, view) would build on its first use there (arguments,
+        scratch, every slot of the output ring: ~0.3 ms of host time and a dozen allocations). The pipelined runner calls
+        it for each of its side streams when it sees the first batch, so that no launch inside a timed window pays it."""
+        sa = self._cloud_layers[0]
+        sa0 = getattr(sa, '_sa0', None)
+        if sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda or x.shape[0] % 2 \
+                or x.shape[2] != self._input_dim or os.environ.get('DCLR_CLOUD_FUSED', '1') == '0':
+            return False
+        per, nb, _ = view if view is not None else (x.shape[0] // 2, 1, 0)
+        plan = self._cloud_plan(sa0, x, per, nb)
+        if plan is None:
+            return False
+        plan.fill_ring()
+        return True
+
     def merge_rows(self, f_rows: torch.Tensor, pairs: int, events=None, prep=None,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
@@ -613,6 +755,7 @@ class DeepCLR(BaseModel):
                                "outputs differ from the f32 matrix path by {:.3g}; run this checkpoint with "
                                "DCLR_PRECISION=f32".format(peak, err))
         self._range_ok = self._range_key()
+        self._merge_plan(f_rows, pairs)             # the next forward of this shape takes the one-call path: build its plan now
         return y16 if out is None else out.copy_(y16)
 
     def _merge_plan(self, f_rows: torch.Tensor, pairs: int):
@@ -621,13 +764,13 @@ class DeepCLR(BaseModel):
                 or not isinstance(head, OutputSimple):
             return None
         # the workspace belongs to one stream: calls enqueued on different streams may run side by side
-        key = (f_rows.device, pairs, self.npoint, ops.PRECISION, torch.cuda.current_stream().cuda_stream)
+        key = (f_rows.device, pairs, self.npoint, ops.PRECISION, lib.stream_ptr())
         plan = self._plans.get(key)
         if plan is None or not plan.current():
             plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint)
             if plan is None:
                 return None
-            if len(self._plans) > 8:
+            if len(self._plans) > 16:
                 self._plans.clear()
             self._plans[key] = plan
         return plan

@@ -55,6 +55,7 @@ class PipelinedForward:
         self._dense_group = dense_group
         self._inputs_ready = inputs_ready
         self._in_place = hasattr(model, '_cloud_layers') and os.environ.get('DCLR_BATCH_VIEW', '1') != '0'   # A/B: 0 = always concatenate
+        self._planned = False                       # launch plans of the side streams built (first _launch)
         self._hold_launch = False                   # dense groups: a full sampling group is launched right AFTER the next
                                                     # dense launch has been enqueued (the host needs ~0.3 ms for the chain)
         self._group_out = None                      # (batches of the running dense group, their outputs)
@@ -91,10 +92,26 @@ class PipelinedForward:
             ev = self._ready.pop(id(b), None)
             if ev is not None:
                 side.wait_event(ev)
+        fused = getattr(self._model, 'cloud_merge_prep', None) if self._ahead == 'knn' else None
+        if fused is not None and not self._planned:
+            # first launch: the launch plans (arguments, scratch, output ring) of EVERY side stream are built now, for this
+            # launch shape -- not one by one inside whatever window the later launches fall into
+            self._planned = True
+            if len(xs) == 1 or self._dense_group:
+                view = ops.batch_view(xs) if (len(xs) > 1 and self._in_place) else None
+                if len(xs) == 1 or view is not None:
+                    for s_ in self._streams:
+                        with torch.cuda.stream(s_), torch.no_grad():
+                            self._model.plan_cloud_forward(xs[0], view)
         with torch.cuda.stream(side), torch.no_grad():
+            prepped = False
             if len(xs) == 1:
-                out = self._model.sample(xs[0])
-                outs = [out if self._ahead == 'sample' else self._model.cloud_feature_rows(xs[0], out)]
+                got = fused(xs[0]) if fused is not None else None      # sampling, set abstraction, stage 1: one foreign call
+                if got is not None:
+                    outs, prepped = [got], True
+                else:
+                    out = self._model.sample(xs[0])
+                    outs = [out if self._ahead == 'sample' else self._model.cloud_feature_rows(xs[0], out)]
             else:
                 if any(b.shape != xs[0].shape for b in xs):
                     raise RuntimeError("batches sampled in one launch must have the same shape")
@@ -103,14 +120,23 @@ class PipelinedForward:
                     # len(xs) * B pairs, so the dense stages can take all of them in one go
                     half = xs[0].shape[0] // 2
                     view = ops.batch_view(xs) if self._in_place else None
+                    got = None
                     if view is not None:
-                        # batches at a constant stride (the same resident tensor, views of one staging chunk): the sampler
-                        # and set abstraction read them where they lie -- no 42 MB concatenation per ten KITTI batches
-                        rows = self._model.cloud_feature_rows(xs[0], self._model.sample(xs[0], view), view)
+                        # batches at a constant stride (the same resident tensor, views of one staging chunk, a ring): the
+                        # sampler and set abstraction read them where they lie -- no 42 MB concatenation per ten KITTI
+                        # batches -- and the whole chain is one foreign call where the model offers it
+                        got = fused(xs[0], view) if fused is not None else None
+                        if got is None:
+                            rows = self._model.cloud_feature_rows(xs[0], self._model.sample(xs[0], view), view)
                     else:
                         big = torch.cat([b[:half] for b in xs] + [b[half:] for b in xs])
-                        rows = self._model.cloud_feature_rows(big, self._model.sample(big))
-                    prep = self._model.merge_prep(rows, half * len(xs))
+                        got = fused(big) if fused is not None else None
+                        if got is None:
+                            rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+                    if got is not None:
+                        rows, prep = got
+                    else:
+                        prep = self._model.merge_prep(rows, half * len(xs))
                     done = torch.cuda.Event()
                     done.record(side)
                     for b in xs:
@@ -120,7 +146,7 @@ class PipelinedForward:
                 big = torch.cat(xs)
                 rows = self._model.cloud_feature_rows(big, self._model.sample(big))
                 outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
-            if self._ahead == 'knn':
+            if self._ahead == 'knn' and not prepped:
                 outs = [(rows, self._model.merge_prep(rows, b.shape[0] // 2)) for b, rows in zip(xs, outs)]
             done = torch.cuda.Event()
             done.record(side)
@@ -151,7 +177,6 @@ class PipelinedForward:
         """Pose outputs (B, label_dim) for batch `x` (written into `out` if given). `upcoming` lists later batches (oldest first) that are
         not yet being sampled; as many as fit the pipeline depth are started before this batch's dense
         stages are enqueued, so they run beside them."""
-        main = torch.cuda.current_stream()
         ready = None
         if self._group_out is not None and self._group_out[0] and self._group_out[0][0] is x:
             # a batch of the dense group already enqueued: its outputs are a slice of that launch's result
@@ -166,6 +191,7 @@ class PipelinedForward:
             self._hold_launch = False
             y = y_all[pos * (x.shape[0] // 2):(pos + 1) * (x.shape[0] // 2)]
             return y if out is None else out.copy_(y)
+        main = torch.cuda.current_stream()
         if not self._pending and self._waiting and self._waiting[0] is x:
             self._launch()                                   # end of a stream of batches: the group never filled
         if self._pending and isinstance(self._pending[0][0], list) and self._pending[0][0][0] is x:

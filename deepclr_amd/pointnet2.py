@@ -155,6 +155,13 @@ class PointnetSAModuleMSG(nn.Module):
             raise NotImplementedError("sample()/forward_rows() belong to the fused kernel; this module runs composed")
         return ops.fps_clouds_grouped(clouds, self.npoint, view)
 
+    def _range_key(self):
+        return tuple((p.data_ptr(), p._version) for p in flat_parameters(self))
+
+    def range_unchecked(self) -> bool:
+        """True until a range-checked split-f16 pass has succeeded for the current weights (forward_rows)."""
+        return self._range_ok != self._range_key()
+
     def forward_rows(self, clouds: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68); sample = self.sample(clouds)."""
         if sample is None:
@@ -166,7 +173,7 @@ class PointnetSAModuleMSG(nn.Module):
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':
             # split-f16 operands clamp at +-65504: the first call after the weights changed (or every call with
             # CHECK_RANGE = 'always') also runs the f32 matrix instructions and compares (two host syncs, once)
-            key = tuple((p.data_ptr(), p._version) for p in flat_parameters(self))
+            key = self._range_key()
             if ops.CHECK_RANGE == 'always' or key != self._range_ok:
                 want = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, precision='f32', view=view)
                 err, scale = float((rows - want).abs().max()), float(want.abs().max())

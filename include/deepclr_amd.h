@@ -309,6 +309,38 @@ typedef struct DclrMergeArgs {
 } DclrMergeArgs;
 int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
 
+/* ---- the per-cloud stages of one launch group in one call ------------------------------------------------
+ * Clouds -> rows F (-> the per-point halves of flow layer 1 and the kNN lists): the launches DeepCLR.forward makes
+ * before the dense stages (reference: deepclr.py:488-521 cloud_features -> SetAbstraction, then the grouping half of
+ * MotionEmbedding, deepclr.py:149-171) enqueued back to back on one stream -- dclr_fps_clouds_grouped_batched,
+ * dclr_sa_msg_fused_batched and, when `merge` is given, dclr_merge_forward with stages = 1 on the rows just written
+ * (merge->f_rows and merge->stages are ignored: the call uses f_rows and 1). Exists for the same reason as
+ * dclr_merge_forward: at ~0.2 ms of GPU time per batch the ~0.3 ms of host time the separate calls cost at every
+ * sampling launch is exposed whenever the pipeline starts from an idle chip.
+ * fps_idx, group_pts, group_box, slice_box, workspace: the caller's scratch (shapes as in the batched entries; they may be
+ * reused by the next call on the same stream); f_rows (b * npoint, DCLR_F_STRIDE) is the product.
+ * events: NULL, or DCLR_CLOUD_EVENTS hipEvent_t handles recorded on `stream` (start, after sampling, after set
+ * abstraction); merge_events: NULL or as dclr_merge_forward (only the stage-1 slots are recorded). */
+#define DCLR_CLOUD_MAX_SCALES 4
+#define DCLR_CLOUD_EVENTS 3
+typedef struct DclrCloudArgs {
+    int b, n, c, npoint;                    /* clouds of the call (all batches), points per cloud, columns, samples */
+    int pairs_per_batch, n_batches;         /* as dclr_fps_clouds_grouped_batched: b == 2 * pairs_per_batch * n_batches */
+    long long batch_stride;
+    int f16, n_scales;                      /* f16 != 0: set abstraction layers 2, 3 on split-f16 operands */
+    float radii[DCLR_CLOUD_MAX_SCALES];
+    int nsamples[DCLR_CLOUD_MAX_SCALES];
+    const float *mlp[DCLR_CLOUD_MAX_SCALES];        /* device: [W1 b1 W2 b2 W3 b3] per scale, as dclr_sa_msg_fused */
+    const float *clouds;                    /* first batch */
+    int32_t *fps_idx;                       /* scratch (b, npoint) */
+    float *group_pts, *group_box, *slice_box;       /* scratch; slice_box may be NULL */
+    void *workspace;                        /* scratch for n > 16384, else ignored */
+    long long workspace_bytes;
+    float *f_rows;                          /* out */
+    const DclrMergeArgs *merge;             /* optional: stage 1 of dclr_merge_forward on f_rows (pairs = b / 2) */
+} DclrCloudArgs;
+int dclr_cloud_forward(const DclrCloudArgs *args, void *const *events, void *const *merge_events, dclr_stream_t stream);
+
 /* ---- scan preparation (reference: CPU transforms run per sample before the model) -----------------------
  * One order-preserving pass over a raw scan raw (n_raw, c_raw): keep rows start, start+nth, ...
  * (SystematicErasing, /root/reference/deepclr/data/transforms/transforms.py:244-268), of those the rows with

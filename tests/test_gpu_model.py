@@ -1017,3 +1017,36 @@ def test_unfilled_knn_slots_raise_on_the_checked_forward_and_are_masked_after(mo
         e = ops.flow_embedding_fused_f16(f_rows, far, pt, ps, p['w1a'], p['b1'], p['w2h'], p['b2'], p['w3h'], p['b3'], flow._radius)
         y_far = model._merge_layers[1].forward_rows(e, pairs)
     assert torch.isfinite(y[0]).all() and torch.equal(y[0], y_far[0])
+
+
+@pytest.mark.parametrize('kind, pairs, n, batches', [('kitti', 2, 2048, 1), ('kitti', 2, 16384, 3), ('modelnet', 4, 2048, 2),
+                                                     ('kitti', 1, 20000, 2)])
+def test_cloud_forward_one_call_equals_the_separate_launches(kind, pairs, n, batches):
+    """dclr_cloud_forward (sampling -> set abstraction -> layer-1 halves + kNN behind one foreign call, what the pipelined
+    runner enqueues per sampling group) against the same stages called one by one: identical rows, identical stage-1
+    buffers, identical poses; batches read in place through a view of one chunk."""
+    cfg = synthetic.model_cfg(kind)
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=5))
+    chunk = torch.stack([torch.from_numpy(synthetic.make_batch(kind, pairs, n, first_pair=10 * i)) for i in range(batches)]).to(DEV)
+    xs = [chunk[i] for i in range(batches)]
+    view = ops.batch_view(xs) if batches > 1 else None
+    with torch.no_grad():
+        assert model.cloud_merge_prep(xs[0], view) is None              # weights not range-checked yet: the caller's fallback
+        rows_ref = model.cloud_feature_rows(xs[0], model.sample(xs[0], view), view)
+        y_ref = model.merge_rows(rows_ref, pairs * batches).clone()      # (the first, checked forward)
+        prep_ref = model.merge_prep(rows_ref, pairs * batches)
+        got = model.cloud_merge_prep(xs[0], view)
+        assert got is not None
+        rows, prep = got
+        assert torch.equal(rows, rows_ref)
+        for a, b in zip(prep[:3], prep_ref[:3]):
+            assert torch.equal(a, b)
+        y = model.merge_rows(rows, pairs * batches, prep=prep)
+        prep.release()
+        assert torch.equal(y, y_ref)
+        # the ring hands the slot out again only behind its release event; a second call must not disturb the first result
+        rows2, prep2 = model.cloud_merge_prep(xs[0], view)
+        assert rows2.data_ptr() != rows.data_ptr() and torch.equal(rows2, rows_ref)
+        for i in range(batches):                                         # and every batch against its own plain forward
+            yi, _, _ = model(xs[i])
+            assert torch.equal(y[i * pairs:(i + 1) * pairs], yi)
