@@ -360,26 +360,49 @@ def load_traffic():
     return doc.get('configs', {}), 'profiles/pmc_traffic.json @ commit {}'.format(doc.get('commit', '?'))
 
 
-def cpu_baseline(cfg, sd, kind: str, points: int, budget_s: float = 15.0):
-    """The oracle (a port: the reference has no CPU path) on this host's cores."""
+def traffic_for(traffic: dict, name: str):
+    """The PMC record of span `name` (`head_conv_fused[80x1024]`): the collection stores the launch size it ran at
+    (`span`), and a figure taken at another launch size (--strict against the grouped run) is not this launch's figure."""
+    tr = traffic.get(kernel_base(name))
+    return tr if tr is not None and tr.get('span') == name else None
+
+
+def cpu_baseline(cfg, sd, kind: str, points: int, budget_s: float = 12.0, pairs_cfg: int = 1):
+    """The oracle (a port: the reference has no CPU path) on this host's cores: batch 1 (the reference's
+    own call pattern; `value`) and, under `batched`, the configuration's batch size ('batch = 1 pair and the
+    config's B (chunked if memory-bound)': at most 8 pairs per call -- the oracle materialises the grouped tensors the
+    reference design does, ~0.9 GB per KITTI pair). The oracle's sampling loop parallelises over clouds, so batch 1 keeps 2 of
+    the threads busy in that leg and the batched call all of them."""
     import oracle
     orc = oracle.build_oracle_model(cfg, sd)
     # a 1-GPU box grants a 16-core share of the host (more threads only oversubscribe it)
     threads = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(threads)
     oracle.primitives.set_threads(threads)
-    x = torch.from_numpy(synthetic.make_batch(kind, 1, points))
-    orc(x)                                           # warm-up (library init, allocator)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        orc(torch.from_numpy(synthetic.make_batch(kind, 1, points, first_pair=done + 1)))
-        done += 1
-        elapsed = time.perf_counter() - t0
-        if elapsed > budget_s or done >= 64:
-            break
-    return {'value': done / elapsed, 'unit': 'scan-pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': '{} pairs of 2x{} points, batch 1, fp32, {:.1f} s wall; torch intra-op + OpenMP threads = {}'
-                      .format(done, points, elapsed, threads)}
+
+    def leg(batch, budget):
+        orc(torch.from_numpy(synthetic.make_batch(kind, batch, points)))             # warm-up (library init, allocator)
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            orc(torch.from_numpy(synthetic.make_batch(kind, batch, points, first_pair=(calls + 1) * batch)))
+            calls += 1
+            elapsed = time.perf_counter() - t0
+            if elapsed > budget or calls * batch >= 64:
+                break
+        return calls * batch, elapsed
+
+    done, elapsed = leg(1, budget_s)
+    out = {'value': done / elapsed, 'unit': 'scan-pairs/s', 'cores': threads, 'kind': 'port',
+           'sample': '{} pairs of 2x{} points, batch 1, fp32, {:.1f} s wall; torch intra-op + OpenMP threads = {}'
+                     .format(done, points, elapsed, threads)}
+    batch = min(pairs_cfg, 8)
+    if batch > 1:
+        done_b, elapsed_b = leg(batch, budget_s)
+        out['batched'] = {'value': done_b / elapsed_b, 'unit': 'scan-pairs/s', 'batch': batch, 'cores': threads,
+                          'sample': '{} pairs of 2x{} points in calls of {} pairs{}, fp32, {:.1f} s wall'.format(
+                              done_b, points, batch, '' if batch == pairs_cfg else ' (the configuration\'s {} pairs chunked)'
+                              .format(pairs_cfg), elapsed_b)}
+    return out
 
 
 def parse_args(argv=None):
@@ -411,6 +434,11 @@ def parse_args(argv=None):
                     help='gauss: SURVEY.md 8(d) Gaussian clouds (headline); ring: LiDAR-density ring scans (KITTI configs)')
     ap.add_argument('--latency', action='store_true',
                     help='one pair per ModelInferenceHelper.predict call (pairwise and sequential), per-pair ms')
+    ap.add_argument('--same-batch', action='store_true',
+                    help='feed the SAME resident batch every step (rounds 1-3; scripts/timing.py:27-34 does that too) instead '
+                         'of a resident ring of distinct batches: the batches of a grouped launch then alias in memory')
+    ap.add_argument('--pose-budget', type=float, default=40.0,
+                    help='seconds of CPU oracle time for the pose check of the last two launch groups (outside the timed region)')
     ap.add_argument('--cpu-stub', action='store_true',
                     help='no GPU: gloo process group and a stand-in compute function (tests of the multi-rank plumbing)')
     ap.add_argument('--gather-every', type=int, default=None,
@@ -490,8 +518,9 @@ class StubModel:
         return float(1000 * rank + step)
 
 
-def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool):
-    """max |M_hip - M_oracle| on the 4x4 for EVERY pair of the step (oracle on the host, outside the timed region)."""
+def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool, rows=None):
+    """max |M_hip - M_oracle| on the 4x4 for the pairs of one step (all of them, or the output rows listed in `rows`); the
+    oracle runs on the host, outside the timed region."""
     import oracle
     from oracle import labels as olabels
     lt = LabelType.POSE3D_DUAL_QUAT
@@ -499,7 +528,7 @@ def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool):
     x_cpu, y_cpu = x.cpu(), y.cpu().numpy()
     deltas = []
     n_out = y_cpu.shape[0]
-    for row in range(n_out):
+    for row in (range(n_out) if rows is None else rows):
         if sequence:                                   # output row r pairs frames r, r + 1 of the chunk (row 0: carried frame)
             if row == 0:
                 continue
@@ -509,6 +538,24 @@ def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool):
         y_ref = orc(x_cpu[clouds])
         deltas.append(float(np.abs(lt.to_matrix(y_cpu[row]) - olabels.dual_quat_to_matrix(y_ref[0].numpy())).max()))
     return deltas
+
+
+def pose_check(recent, cfg, sd, pairs_cfg: int, sequence: bool, budget_s: float):
+    """Pose check over the steps in `recent` = [(batch, outputs)] (the last two launch groups): every pair while the CPU
+    budget lasts, dealt so that every batch is covered before any batch gets a second pair. Returns (deltas, pairs
+    available, batches covered)."""
+    total = sum(y.shape[0] for _, y in recent)
+    if sequence or len(recent) == 1:
+        d = pose_deltas(recent[-1][1], recent[-1][0], cfg, sd, pairs_cfg, sequence)
+        return d, total, 1
+    deltas, covered, t0 = [], set(), time.perf_counter()
+    for row in range(pairs_cfg):
+        for i, (xb, yb) in enumerate(recent):
+            if time.perf_counter() - t0 > budget_s and len(covered) == len(recent):
+                return deltas, total, len(covered)
+            deltas += pose_deltas(yb, xb, cfg, sd, pairs_cfg, False, rows=[row])
+            covered.add(i)
+    return deltas, total, len(covered)
 
 
 def run_latency(args, model, cfg, sd, kind, points, dev):
@@ -626,9 +673,23 @@ def run(args):
         print(json.dumps(result), flush=True)
         return
 
+    batches = None
     if not stub:
-        x_host = torch.from_numpy(synthetic.make_batch(cloud_kind, pairs_cfg, points, first_pair=rank * pairs_cfg))
-        x = x_host.to(dev)
+        # The timed loop walks a RESIDENT RING of distinct batches (views of one chunk, so that grouped launches read
+        # their batches in place at a real stride): one more launch group than the pipeline holds, so no batch is in flight
+        # twice. --same-batch: one batch every step (rounds 1-3); the batches of a grouped launch then alias in memory and
+        # the sampler's / set abstraction's cloud reads hit in L2.
+        n_ring = 1 if (args.same_batch or args.sequence) else \
+            max(2, (1 if args.no_overlap else args.depth + 1) * args.group)
+        x_host = torch.from_numpy(np.stack([
+            synthetic.make_batch(cloud_kind, pairs_cfg, points, first_pair=(rank * n_ring + i) * pairs_cfg)
+            for i in range(n_ring)]))
+        chunk = x_host.to(dev)
+        batches = [chunk[i] for i in range(n_ring)]             # the SAME view objects every lap: the runner matches by identity
+        x_host = x_host[0]
+        x = batches[0]
+    else:
+        batches = [x]
 
     pairs_per_step = pairs_cfg
     feeder = None
@@ -651,13 +712,13 @@ def run(args):
             raise SystemExit('bench.py: --h2d runs through the pipelined runner')
         # the loader's side: chunks of consecutive batches in pinned memory (here: the same batch, `chunk` times)
         feeder = HostBatchFeeder(runner, x)
-        host_chunk = torch.stack([x_host] * feeder.chunk).pin_memory()
+        host_chunk = torch.stack([batches[i % len(batches)].cpu() for i in range(feeder.chunk)]).pin_memory()
         while feeder.pending() < args.depth * args.group and feeder.room():
             feeder.feed(host_chunk)
         feeder.fill()
     elif runner is not None:
-        for _ in range(args.depth * args.group):
-            runner.prefetch(x, flush=False)
+        for i in range(args.depth * args.group):
+            runner.prefetch(batches[i % len(batches)], flush=False)
 
     if args.gather_every is None:            # one all-gather per dense group: its outputs are written in place
         args.gather_every = args.group if getattr(runner, '_dense_group', False) else 4
@@ -670,6 +731,9 @@ def run(args):
         ranks_seen = [int(v) for v in seen.cpu()]
 
     in_place_left = [0]
+    stepped = [0]                                # steps taken so far = index (mod the ring) of the next batch
+    recent = []                                  # (batch, outputs) of the latest steps: two launch groups for the pose check
+    keep_recent = 2 * args.group if (getattr(runner, '_dense_group', False) and not args.sequence) else 1
 
     def step():
         # the outputs go straight into the all-gather's send buffer where the runner allows it: one slot per step,
@@ -679,18 +743,27 @@ def run(args):
             if feeder.room() and feeder.pending() <= args.depth * args.group:
                 feeder.feed(host_chunk)                        # one copy per `chunk` steps, on the copy stream
             y = feeder.step()
+            recent.append((batches[(stepped[0] % feeder.chunk) % len(batches)], y))
         elif runner is not None:
+            cur = batches[stepped[0] % len(batches)]
             if gather is not None and not args.sequence:
-                span = runner.group_start(x)
+                span = runner.group_start(cur)
                 if span == 0 and in_place_left[0] == 0 and not runner._dense_group:
                     out, in_place_left[0] = gather.slot(), 1
                 elif span > 0 and gather.filled + span <= gather.every:
                     out = gather.send[gather.filled:gather.filled + span].view(span * pairs_per_step, -1)
                     in_place_left[0] = span
-            y = runner.step(x, upcoming=[x], out=out)
+            nxt = runner.prefetched if not args.sequence else stepped[0] + 1      # the oldest batch not yet handed in
+            y = runner.step(cur, upcoming=[batches[nxt % len(batches)]], out=out)
+            recent.append((cur, y))
         else:
+            cur = batches[stepped[0] % len(batches)]
             with torch.no_grad():
-                y, _, _ = model(x)
+                y, _, _ = model(cur)
+            recent.append((cur, y))
+        stepped[0] += 1
+        if len(recent) > keep_recent:
+            del recent[0]
         if gather is not None:
             if in_place_left[0] > 0:
                 in_place_left[0] -= 1
@@ -715,7 +788,8 @@ def run(args):
             g = args.group if (args.group > 1 and not args.sequence and runner is not None) else 1
             dense_g = g if getattr(runner, '_dense_group', False) else 1
             half = x.shape[0] // 2
-            xs = torch.cat([x[:half]] * g + [x[half:]] * g) if dense_g > 1 else torch.cat([x] * g)
+            grp = [batches[i % len(batches)] for i in range(g)]
+            xs = torch.cat([b[:half] for b in grp] + [b[half:] for b in grp]) if dense_g > 1 else torch.cat(grp)
             for _ in range(iters):
                 if args.sequence:
                     f_rows = model.cloud_feature_rows(x)
@@ -740,6 +814,48 @@ def run(args):
         summary = solo.summary()
         solo.close()
         return summary, rounds
+
+    def latency_pass(n_steps):
+        """Untimed pass through the SAME pipeline: per batch, the time from the step in which the runner accepted it
+        (prefetch) to the moment its pose outputs were complete on the device. The host keeps enqueueing as in the timed
+        loop; a watcher thread waits on one event per step (recorded behind that step's outputs) and stamps the clock."""
+        import threading
+        import queue
+        if runner is None or feeder is not None or args.sequence:
+            return None
+        q, done_at = queue.Queue(), {}
+
+        def watch():
+            torch.cuda.set_device(dev)
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                seq, ev = item
+                ev.synchronize()
+                done_at[seq] = time.perf_counter()
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
+        submitted = {}
+        first = stepped[0]
+        for _ in range(n_steps):
+            before, t = runner.prefetched, time.perf_counter()
+            step()
+            for seq in range(before, runner.prefetched):
+                submitted[seq] = t
+            ev = torch.cuda.Event()
+            ev.record()
+            q.put((stepped[0] - 1, ev))
+        q.put(None)
+        th.join()
+        sync()
+        lat = sorted(1e3 * (done_at[sq] - submitted[sq]) for sq in done_at if sq in submitted and sq >= first)
+        if not lat:
+            return None
+        return {'median': lat[len(lat) // 2], 'p90': lat[int(0.9 * (len(lat) - 1))], 'max': lat[-1], 'min': lat[0],
+                'batches': len(lat),
+                'definition': 'per batch: host time at which the runner accepted it for sampling -> its pose outputs complete '
+                              'on the device (event wait in a watcher thread); untimed pass over the same pipeline'}
 
     if args.alone_only:
         # profiling aid (profiles/collect.py): no timed window, only the launches one after another at the launch
@@ -784,7 +900,10 @@ def run(args):
         print('host trace (us after t0, per step): ' + ' '.join('%.0f' % (1e6 * v) for v in host_trace) +
               ' | closing fence returned at %.0f' % (1e6 * elapsed), file=sys.stderr)
     ops.TIMER = None
-    alone, fps_rounds = None, None
+    recent_kept = list(recent)                   # the last two launch groups of the TIMED loop (pose check below)
+    alone, fps_rounds, latency = None, None, None
+    if rank == 0 and not stub and world == 1:
+        latency = latency_pass((args.depth + 3) * args.group if args.group > 1 else 4 * args.depth + 8)   # > the batches in flight
     if timer is not None and rank == 0:
         alone, fps_rounds = solo_pass(6)
     if use_dist:
@@ -836,7 +955,7 @@ def run(args):
                 else:
                     achieved, peak, unit = units / sec / 1e9, HBM_PEAK_GBS, 'GB/s'
                 solo_us = alone[name]['avg_us'] if alone and name in alone else None
-                tr = traffic.get(kernel_base(name))
+                tr = traffic_for(traffic, name)
                 out = {'kernel': name, 'bound': bound, 'achieved': achieved, 'peak': peak, 'peak_basis': basis,
                        'unit': unit, 'frac': achieved / peak,
                        'traffic': None if tr is None else tr.get('bytes_per_launch'),
@@ -846,6 +965,10 @@ def run(args):
                        # this kernel's launches in the timed region x its average duration / the region
                        'share_of_step': kernels[name]['avg_us'] * 1e-6 * kernels[name]['launches'] / elapsed,
                        'stream': 'main' if kernels[name]['main_stream'] else 'side (overlapped)'}
+                if bound == 'mfma':
+                    # matrix-pipe busy fraction of the launch running alone: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
+                    # kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs (a separate --pmc pass, profiles/collect.py)
+                    out['mfma_busy'] = None if tr is None else tr.get('mfma_busy')
                 if solo_us is not None:        # CU-time: what the launch costs the chip when it runs alone
                     out['cu_us_per_pair_alone'] = solo_us * min(1.0, _workgroups(name, cfg) / 256.0) / _pairs_in(name)
                 out.update(extra)
@@ -878,7 +1001,10 @@ def run(args):
                                        'kitti_00-06' if kind == 'kitti' else 'modelnet40'),
                        'id': args.config, 'mode': mode, 'clouds': args.clouds,
                        'input': ('pinned host memory, copied inside the loop in chunks of {} batches'.format(feeder.chunk)
-                                 if args.h2d else 'resident in HBM'),
+                                 if args.h2d else 'resident in HBM: ' + (
+                                     'the same batch every step' if len(batches) == 1 else
+                                     'a ring of {} distinct batches ({:.0f} MB), walked in order'.format(
+                                         len(batches), len(batches) * x.numel() * 4 / 1e6))),
                        'pairs_per_gpu': pairs_per_step, 'points_per_cloud': points,
                        'parallelism': 'dp%d' % world,
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
@@ -891,6 +1017,8 @@ def run(args):
                                                          'bytes_per_rank': int(gather.send.numel() * 4)},
             'roofline': roofline,
         }
+        if latency is not None:
+            result['latency_ms_per_batch'] = latency
         if feeder is not None:
             copied = feeder.bytes_copied - copied0
             result['h2d'] = {'bytes_per_step': copied / args.steps, 'gb_per_s': copied / elapsed / 1e9,
@@ -905,12 +1033,15 @@ def run(args):
         if kernels is not None:
             result['kernels_us'] = {k: round(v['avg_us'], 1) for k, v in sorted(kernels.items())}
         if world == 1 and not args.no_cpu_baseline:
-            # pose check of EVERY pair of the last step against the oracle (outside the timed region)
-            deltas = pose_deltas(y, x, cfg, sd, pairs_cfg, args.sequence)
+            # pose check of the last two launch groups of the timed loop against the oracle (outside the timed region):
+            # every batch of them, as many pairs per batch as the CPU budget allows
+            deltas, available, covered = pose_check(recent_kept or [(x, y)], cfg, sd, pairs_cfg, args.sequence, args.pose_budget)
             result['pose_delta_vs_oracle'] = float(np.mean(deltas))
             result['pose_delta_max'] = float(np.max(deltas))
             result['pose_delta_pairs'] = len(deltas)
-            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points)
+            result['pose_delta_of'] = {'pairs_in_the_last_two_groups': available, 'batches_covered': covered,
+                                       'batches': len(recent_kept) or 1}
+            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points, pairs_cfg=pairs_cfg)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

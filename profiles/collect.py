@@ -177,6 +177,21 @@ def main():
                 shutil.copy(path, os.path.join(out, '{}_{}_alone_kernel_stats.csv'.format(args.tag, cfg)))
         if args.skip_pmc:
             continue
+        # the launch sizes of this configuration's spans (`fps_clouds[160x16384]` ...): bench.py attaches a figure only to
+        # the span it was collected on
+        names_log = os.path.join(out, '{}_{}_bench_line.json'.format(args.tag, cfg))
+        run(bench, names_log)
+        with open(names_log) as fh:
+            rows_ = [l for l in fh.read().splitlines() if l.startswith('{')]
+        line = json.loads(rows_[-1]) if rows_ else {}
+        with open(names_log, 'w') as fh:
+            fh.write((rows_[-1] if rows_ else '') + '\n')
+        full_name = {}
+        for name in line.get('kernels_us', {}):
+            base = name.split('[')[0]
+            full_name.setdefault(base, name)
+            if len(name) > len(full_name[base]) or name > full_name[base]:      # several sizes (a partial first group): the larger
+                full_name[base] = name
         spans = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             d = os.path.join(out, 'raw_pmc_{}_{}'.format(cfg, counter))
@@ -185,10 +200,23 @@ def main():
             for span, (avg, cnt) in per_span_average(d, counter).items():
                 spans.setdefault(span, {})[counter + '_KB'] = avg
                 spans[span]['launches_' + counter] = cnt
+        # matrix-pipe busy cycles of the launches running ALONE (the same launch sizes one after another): a pass of its
+        # own, program directly after `--`, no trace domain beside --kernel-trace
+        d = os.path.join(out, 'raw_pmc_{}_mfma'.format(cfg))
+        run(['rocprofv3', '--kernel-trace', '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', '--output-format', 'csv', '-d', d,
+             '--', py, 'bench.py', '--config', cfg, '--alone-only', '6'], os.path.join(out, 'pmc_{}_mfma.log'.format(cfg)))
+        busy, active = per_span_average(d, 'SQ_VALU_MFMA_BUSY_CYCLES'), per_span_average(d, 'GRBM_GUI_ACTIVE')
+        for span in busy:
+            if span in active and active[span][0] > 0 and busy[span][0] > 0:
+                rec = spans.setdefault(span, {})
+                rec['SQ_VALU_MFMA_BUSY_CYCLES'], rec['GRBM_GUI_ACTIVE'] = busy[span][0], active[span][0]
+                # busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                rec['mfma_busy'] = busy[span][0] / (1024.0 * active[span][0] / 8.0)
         for span, rec in spans.items():
             f, w = rec.get('FETCH_SIZE_KB', 0.0) * 1024, rec.get('WRITE_SIZE_KB', 0.0) * 1024
             rec['bytes_per_launch_raw'] = f + w
             rec['bytes_per_launch'] = f * (fetch_factor or 2.0) + w
+            rec['span'] = full_name.get(span)
         doc['configs'][cfg] = spans
         print(cfg, json.dumps(spans), flush=True)
     if not args.skip_pmc:

@@ -226,3 +226,46 @@ def test_traffic_figures_attach_only_to_the_kernels_they_were_measured_on(bench,
                                 'configs': {'c2': {'head_conv_fused': {'bytes_per_launch': 123}}}}))
     got, why = bench.load_traffic()
     assert got['c2']['head_conv_fused']['bytes_per_launch'] == 123 and 'abc' in why
+
+
+def test_traffic_is_keyed_by_the_launch_size_it_was_collected_at(bench):
+    """profiles/collect.py stores the full span name beside each figure; a launch of another size gets nothing."""
+    traffic = {'head_conv_fused': {'bytes_per_launch': 2.79e8, 'span': 'head_conv_fused[80x1024]', 'mfma_busy': 0.41},
+               'knn_rows': {'bytes_per_launch': 2.7e7}}                                      # an old record without a span
+    assert bench.traffic_for(traffic, 'head_conv_fused[80x1024]')['mfma_busy'] == 0.41
+    assert bench.traffic_for(traffic, 'head_conv_fused[8x1024]') is None                     # --strict launch: not its figure
+    assert bench.traffic_for(traffic, 'knn_rows[80x1024x20]') is None
+    assert bench.traffic_for(traffic, 'fps_clouds[160x16384]') is None
+
+
+def test_pose_check_covers_every_batch_before_any_batch_gets_a_second_pair(bench, monkeypatch):
+    calls = []
+
+    def fake(y, x, cfg, sd, pairs_cfg, sequence, rows=None):
+        calls.append((int(x[0]), tuple(rows)))
+        return [1e-6]
+    monkeypatch.setattr(bench, 'pose_deltas', fake)
+    import torch
+    recent = [(torch.tensor([i]), torch.zeros(8, 8)) for i in range(5)]
+    deltas, available, covered = bench.pose_check(recent, None, None, 8, False, budget_s=0.0)   # no budget: one pair per batch
+    assert available == 40 and covered == 5 and len(deltas) == 5
+    assert calls == [(i, (0,)) for i in range(5)]
+    calls.clear()
+    deltas, _, covered = bench.pose_check(recent, None, None, 8, False, budget_s=1e9)           # ample budget: every pair
+    assert len(deltas) == 40 and covered == 5 and calls[5] == (0, (1,))
+
+
+def test_cpu_baseline_reports_batch_one_and_the_configurations_batch(bench):
+    from deepclr_amd import synthetic
+    cfg = synthetic.model_cfg('kitti')
+    out = bench.cpu_baseline(cfg, synthetic.random_state_dict(cfg, seed=0), 'kitti', 256, budget_s=0.2, pairs_cfg=8)
+    assert out['kind'] == 'port' and out['value'] > 0 and out['cores'] >= 1 and 'batch 1' in out['sample']
+    assert out['batched']['batch'] == 8 and out['batched']['value'] > 0 and 'calls of 8 pairs' in out['batched']['sample']
+    one = bench.cpu_baseline(cfg, synthetic.random_state_dict(cfg, seed=0), 'kitti', 256, budget_s=0.1, pairs_cfg=1)
+    assert 'batched' not in one
+
+
+def test_new_arguments_parse(bench):
+    a = bench.parse_args(['--same-batch', '--pose-budget', '5'])
+    assert a.same_batch and a.pose_budget == 5.0
+    assert not bench.parse_args([]).same_batch
