@@ -73,16 +73,17 @@ class SetAbstraction(DeepCLRModule):
         self._output_feat_dim = int(np.sum([spec[-1] for spec in mlps[-1]]))
         self._sa0 = PointnetSAModuleMSG(npoint=npoint[0], radii=radii[0], nsamples=nsamples[0],
                                         mlps=[[feat_in, *spec] for spec in mlps[0]], use_xyz=True, bn=batch_norm)
-        if not self._sa0.fused:
-            raise NotImplementedError("level 0 must fit the fused kernel: xyz + <= 1 feature, mlp widths [16, 16, 32]")
         if len(npoint) == 2:
             self._sa1 = PointnetSAModuleMSG(npoint=npoint[1], radii=radii[1], nsamples=nsamples[1],
                                             mlps=[[*spec] for spec in mlps[1]], use_xyz=True, bn=batch_norm)
-            if self._output_feat_dim > FEAT:
-                raise NotImplementedError("at most {} feature channels per point".format(FEAT))
         else:
             self._sa1 = None
         self.npoint = npoint[-1]
+        # Row pipeline (rows F, 64 feature columns): level 0 on the fused kernel -- xyz + <= 1 feature, mlp widths
+        # [16, 16, 32], every shipped configuration -- and at most 64 output features. Any other shape the reference
+        # accepts (deepclr.py:50-70: any `mlps`, any number of input features) runs composed from the level-1 HIP
+        # operators in the reference's channel layout (forward()).
+        self.rows_path = self._sa0.fused and self._output_feat_dim <= FEAT
 
     def output_dim(self) -> int:
         return 3 + self._output_feat_dim
@@ -92,6 +93,9 @@ class SetAbstraction(DeepCLRModule):
 
     def forward_rows(self, clouds: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """(2B, N, C) point-major clouds -> rows F."""
+        if not self.rows_path:
+            raise NotImplementedError("this set-abstraction shape runs composed (forward()); the row pipeline needs level 0 "
+                                      "as xyz + <= 1 feature with mlp widths [16, 16, 32] and <= 64 output features")
         rows = self._sa0.forward_rows(clouds, sample, view)
         if self._sa1 is None:
             return rows
@@ -102,8 +106,16 @@ class SetAbstraction(DeepCLRModule):
 
     def forward(self, clouds: torch.Tensor, *_args: Any) -> torch.Tensor:
         """(2B, C, N) channel-major clouds -> (2B, 3 + feat, npoint), as the reference module."""
-        rows = self.forward_rows(clouds.transpose(1, 2).contiguous())
-        return ops.rows_to_channels(rows, clouds.shape[0], self.npoint, self._output_feat_dim)
+        if self.rows_path:
+            rows = self.forward_rows(clouds.transpose(1, 2).contiguous())
+            return ops.rows_to_channels(rows, clouds.shape[0], self.npoint, self._output_feat_dim)
+        # composed (reference: split_features -> _sa0 [-> _sa1] -> merge_features, deepclr.py:88-94)
+        xyz = clouds[:, :3, :].transpose(1, 2).contiguous()
+        feats = clouds[:, 3:, :].contiguous() if clouds.shape[1] > 3 else None
+        xyz, feats = self._sa0(xyz, feats)
+        if self._sa1 is not None:
+            xyz, feats = self._sa1(xyz, feats)
+        return torch.cat((xyz.transpose(1, 2), feats), dim=1).contiguous()
 
 
 # --------------------------------------------------------------------------------------------------
@@ -116,19 +128,22 @@ class MotionEmbeddingBase(nn.Module):
     def __init__(self, input_dim: int, point_dim: int, k: int, radius: float, mlp: List[int],
                  append_features: bool = True, batch_norm: bool = False, **_kwargs: Any):
         super().__init__()
-        if not 0 <= k <= 32:
-            raise NotImplementedError("the fused flow-embedding kernel pads each neighbourhood to 32 rows (k <= 32)")
-        if list(mlp) != [128, 128, 256]:
-            raise NotImplementedError("the fused flow-embedding kernel is built for mlp [128, 128, 256]")
+        if not 0 <= k <= 64:
+            raise NotImplementedError("the kNN search keeps at most 64 neighbours per query (k <= 64)")
+        if point_dim != 3:
+            raise NotImplementedError("three-dimensional points only")
         self._point_dim = point_dim
         self._feat_dim = input_dim - point_dim
-        if self._feat_dim > FEAT:
-            raise NotImplementedError("at most {} feature channels per point".format(FEAT))
+        # Row pipeline (fused kernel, rows F -> rows E): the shipped shape -- mlp [128, 128, 256], k <= 32, <= 64 features.
+        # Any other `mlp` / k <= 64 / feature width the reference accepts (deepclr.py:180-199) runs composed from the
+        # level-1 HIP operators (forward()).
+        self.rows_path = k <= 32 and list(mlp) == [128, 128, 256] and self._feat_dim <= FEAT
         self._append_features = append_features
         self._k, self._radius = int(k), float(radius)
         c_in = point_dim + (2 if append_features else 1) * self._feat_dim
         self._conv = Conv1dMultiLayer([c_in, *mlp], batch_norm=batch_norm)
         self._cache = PackedCache()
+        self._cache_composed = PackedCache()
 
     def output_dim(self) -> int:
         return self._point_dim + self._conv.output_dim()
@@ -157,6 +172,9 @@ class MotionEmbeddingBase(nn.Module):
     def forward_rows(self, f_rows: torch.Tensor, pairs: int, npoint: int, precision: Optional[str] = None) -> torch.Tensor:
         """rows F of [templates..., sources...] -> rows E (pairs*npoint, 264). precision: matrix path of this call
         ('f16x2' / 'f32'); None = ops.PRECISION."""
+        if not self.rows_path:
+            raise NotImplementedError("this flow-embedding shape runs composed (forward()); the row pipeline needs "
+                                      "mlp [128, 128, 256], k <= 32 and <= 64 feature channels")
         precision = precision or ops.PRECISION
         p = self._packed()
         half = pairs * npoint
@@ -187,11 +205,95 @@ class MotionEmbeddingBase(nn.Module):
         return e_rows
 
     def forward(self, clouds0: torch.Tensor, clouds1: torch.Tensor) -> torch.Tensor:
-        """(B, 3+F, P) template / source feature clouds -> (B, 3+256, P), as the reference module."""
+        """(B, 3+F, P) template / source feature clouds -> (B, 3+mlp[-1], P), as the reference module."""
+        if not self.rows_path:
+            return self._forward_composed(clouds0.contiguous(), clouds1.contiguous())
         b, _, npoint = clouds0.shape
         f_rows = ops.channels_to_rows(torch.cat((clouds0, clouds1), dim=0).contiguous(), ops.F_STRIDE)
         e_rows = self.forward_rows(f_rows, b, npoint)
         return ops.rows_to_channels(e_rows, b, npoint, 256)
+
+    def _packed_composed(self):
+        """dclr_linear weights of the composed path. The LAST layer gets one extra input column with weight -1e30: the
+        rows of neighbours beyond the radius (and the rows that pad a neighbourhood to a multiple of 64) carry 1 there,
+        so their outputs are exactly 0 after the ReLU -- what the reference's masked_scatter_ writes (deepclr.py:220-223)
+        -- and the max over the neighbourhood folds into that layer's launch (ops.linear(colmax_groups=...))."""
+        def build():
+            layers = []
+            params = self._conv.affine_params()
+            for j, (w, b) in enumerate(params):
+                w = w.detach().reshape(w.shape[0], -1)
+                last = j == len(params) - 1
+                k_in = w.shape[1] + (1 if last else 0)
+                kp = (k_in + 7) // 8 * 8
+                if last:
+                    w = torch.cat((w, torch.full((w.shape[0], 1), -1.0e30, device=w.device)), dim=1)
+                layers.append((ops.pack_weight(w.contiguous(), kp), b.detach().contiguous(), w.shape[0], kp))
+            return layers
+        return self._cache_composed.get(flat_parameters(self), build)
+
+    def _forward_composed(self, clouds0: torch.Tensor, clouds1: torch.Tensor) -> torch.Tensor:
+        """The reference's own composition (deepclr.py:142-173 or 108-139, then 201-231) on the level-1 HIP operators:
+        dclr_knn -> dclr_group_points -> dclr_linear chain with the radius mask and the max folded into its last launch."""
+        b, c, p0 = clouds0.shape
+        p1 = clouds1.shape[2]
+        d, k = self._point_dim, self._k
+        dev = clouds0.device
+        layers = self._packed_composed()
+        xyz0 = clouds0[:, :d, :].transpose(1, 2).contiguous()                       # (B, P0, 3)
+        if k > 0:
+            if p1 < k:
+                raise RuntimeError("kNN grouping: {} source points, k = {}".format(p1, k))
+            xyz1 = clouds1[:, :d, :].transpose(1, 2).contiguous()
+            row = torch.empty(b * p0 * k, dtype=torch.int64, device=dev)
+            col = torch.empty(b * p0 * k, dtype=torch.int64, device=dev)
+            ops._call('dclr_knn', 'knn', b, p1, p0, k, xyz1.data_ptr(), xyz0.data_ptr(), row.data_ptr(), col.data_ptr(),
+                      lib.stream_ptr())
+            if bool((col < 0).any()):
+                # upstream: torch_cluster.knn returns fewer than k neighbours and .view(2, G, k) fails (deepclr.py:167)
+                raise RuntimeError("kNN grouping: a template point has fewer than k = {} source points within the "
+                                   "search's start distance, or non-finite coordinates".format(k))
+            idx = (col.view(b, p0, k) - (torch.arange(b, device=dev) * p1).view(b, 1, 1)).to(torch.int32)
+        else:                                                                      # GlobalGrouping: all source points, in order
+            k = p1
+            idx = torch.arange(p1, dtype=torch.int32, device=dev).view(1, 1, p1).expand(b, p0, p1)
+        r = (k + 63) // 64 * 64                                                    # rows per neighbourhood (dclr_linear: blocks of 64)
+        c_in = d + (2 if self._append_features else 1) * (c - d)
+        kp0, n_last = layers[0][3], layers[-1][2]
+        out = torch.empty(b, n_last, p0, dtype=torch.float32, device=dev)
+        # template points in chunks that keep the materialised neighbourhood rows below ~256 MB
+        chunk = max(1, min(p0, (1 << 26) // (r * max(kp0, 8) * b)))
+        for q0 in range(0, p0, chunk):
+            q1 = min(p0, q0 + chunk)
+            q = q1 - q0
+            sel = torch.zeros(b, q, r, dtype=torch.int32, device=dev)
+            sel[:, :, :k] = idx[:, q0:q1, :]
+            grouped = ops.grouping_operation(clouds1, sel.contiguous())            # (B, C, q, r)
+            pos_diff = grouped[:, :d] - clouds0[:, :d, q0:q1].unsqueeze(-1)
+            feat_t = clouds0[:, d:, q0:q1].unsqueeze(-1)
+            if self._append_features:
+                merged = torch.cat((pos_diff, feat_t.expand(-1, -1, -1, r), grouped[:, d:]), dim=1)
+            else:
+                merged = torch.cat((pos_diff, grouped[:, d:] - feat_t), dim=1)
+            rows = torch.zeros(b * q * r, kp0, dtype=torch.float32, device=dev)
+            rows[:, :c_in] = merged.permute(0, 2, 3, 1).reshape(-1, c_in)
+            masked = torch.zeros(b, q, r, dtype=torch.bool, device=dev)
+            masked[:, :, k:] = True
+            if self._radius > 0.0:
+                masked[:, :, :k] = torch.norm(pos_diff[:, :, :, :k], dim=1) >= self._radius
+            h = rows
+            for j, (wp, bias, n_out, kp) in enumerate(layers):
+                if j + 1 < len(layers):
+                    ldy = layers[j + 1][3]
+                    h = ops.linear(h, wp, bias, n_out, kp, relu=True, ldy=ldy)
+                    if j + 2 == len(layers):                                       # the mask column of the last layer's input
+                        h[:, n_out] = masked.reshape(-1).to(torch.float32)
+                else:
+                    if len(layers) == 1:
+                        h[:, c_in] = masked.reshape(-1).to(torch.float32)
+                    pooled = ops.linear(h, wp, bias, n_out, kp, relu=True, colmax_groups=b * q)
+            out[:, :, q0:q1] = pooled.view(b, q, n_last).transpose(1, 2)
+        return torch.cat((clouds0[:, :d, :], out), dim=1).contiguous()
 
 
 class MotionEmbedding(DeepCLRModule):
@@ -200,6 +302,10 @@ class MotionEmbedding(DeepCLRModule):
     def __init__(self, **kwargs: Any):
         super().__init__()
         self._embedding = MotionEmbeddingBase(**kwargs)
+
+    @property
+    def rows_path(self) -> bool:
+        return self._embedding.rows_path
 
     def output_dim(self) -> int:
         return self._embedding.output_dim()
@@ -221,8 +327,8 @@ class OutputSimple(DeepCLRModule):
     def __init__(self, input_dim: int, label_type: LabelType, mlp: List[int], linear: List[int],
                  batch_norm: bool = False, dropout: float = 1.0, **_kwargs: Any):
         super().__init__()
-        if input_dim != 3 + 256:
-            raise NotImplementedError("the head consumes flow-embedding rows E (3 + 256 channels)")
+        self.rows_path = input_dim == 3 + 256        # rows E of the fused flow embedding; other widths run composed (forward())
+        self._input_dim = input_dim
         self._label_type = label_type
         self.conv = Conv1dMultiLayer([input_dim, *mlp], batch_norm=batch_norm)
         self.linear = LinearMultiLayer(linear, batch_norm=batch_norm, dropout_keep=dropout, dropout_last=True)
@@ -234,6 +340,7 @@ class OutputSimple(DeepCLRModule):
         self._act = {LabelType.POSE3D_DUAL_QUAT: 2, LabelType.POSE3D_QUAT: 3}.get(label_type, 0)
         self._cache = PackedCache()
         self._cache16 = PackedCache()
+        self._cache_plain = PackedCache()
 
     def output_dim(self) -> int:
         return self._label_type.dim
@@ -303,8 +410,36 @@ class OutputSimple(DeepCLRModule):
         return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """(B, 259, P) -> (B, label_dim)."""
-        return self.forward_rows(ops.channels_to_rows(x.contiguous(), ops.E_STRIDE), x.shape[0])
+        """(B, C, P) -> (B, label_dim)."""
+        if self.rows_path:
+            return self.forward_rows(ops.channels_to_rows(x.contiguous(), ops.E_STRIDE), x.shape[0])
+        # any input width: the conv chain layer by layer on dclr_linear (reference column order, no remap), the max over
+        # points folded into the last launch; a pair's rows are padded to a multiple of 64 with repeats of its first point
+        b, c, p = x.shape
+        layers = self._packed_plain()
+        pp = (p + 63) // 64 * 64
+        pts = x.transpose(1, 2)                                                     # (B, P, C)
+        if pp != p:
+            pts = torch.cat((pts, pts[:, :1, :].expand(-1, pp - p, -1)), dim=1)
+        h = torch.zeros(b * pp, layers[0][3], dtype=torch.float32, device=x.device)
+        h[:, :c] = pts.reshape(-1, c)
+        for j, (wp, bias, n, kp) in enumerate(layers):
+            if j + 1 < len(layers):
+                h = ops.linear(h, wp, bias, n, kp, relu=True, ldy=layers[j + 1][3])
+            else:
+                g = ops.linear(h, wp, bias, n, kp, relu=True, colmax_groups=b)
+        g = self.linear(g)
+        return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
+
+    def _packed_plain(self):
+        def build():
+            layers = []
+            for w, b in self.conv.affine_params():
+                w = w.detach().reshape(w.shape[0], -1)
+                kp = (w.shape[1] + 7) // 8 * 8
+                layers.append((ops.pack_weight(w.contiguous(), kp), b.detach().contiguous(), w.shape[0], kp))
+            return layers
+        return self._cache_plain.get(flat_parameters(self.conv), build)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -601,6 +736,10 @@ class DeepCLR(BaseModel):
         head = _init_module(output, input_dim=merge_layer.output_dim(), label_type=label_type, **kwargs)
         self._cloud_layers = nn.Sequential(cloud)
         self._merge_layers = nn.Sequential(merge_layer, head)
+        # The fused row pipeline (rows F -> rows E -> pose) covers every shipped configuration; a configuration with other
+        # layer widths / k / feature counts runs module by module in the reference's channel layout, every module composed
+        # from the level-1 HIP operators where its own shape is not the fused one.
+        self._rows_path = all(getattr(mod, 'rows_path', False) for mod in (cloud, merge_layer, head))
         self._plans: Dict[Any, Any] = {}
         self._range_ok = None                       # weights key of the last checked forward that passed (ops.CHECK_RANGE)
         if loss is None:
@@ -629,7 +768,9 @@ class DeepCLR(BaseModel):
         if not next(self.parameters()).is_cuda:
             return
         for mod in self.modules():
-            for name in ('packed_mlps', '_packed', '_packed_f16'):
+            names = ('packed_mlps', '_packed', '_packed_f16') if getattr(mod, 'rows_path', True) and self._rows_path \
+                else ('packed_mlps', '_packed_composed', '_packed_plain')
+            for name in names:
                 fn = getattr(mod, name, None)
                 if callable(fn) and mod is not self:
                     fn()
@@ -661,8 +802,8 @@ class DeepCLR(BaseModel):
         two methods one after the other. The pipelined runner's sampling chain: ~0.3 ms of host time per launch otherwise."""
         sa = self._cloud_layers[0]
         sa0 = getattr(sa, '_sa0', None)
-        if sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda or x.shape[0] % 2 \
-                or x.shape[2] != self._input_dim or not x.is_contiguous() or x.dtype != torch.float32 \
+        if not self._rows_path or sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda \
+                or x.shape[0] % 2 or x.shape[2] != self._input_dim or not x.is_contiguous() or x.dtype != torch.float32 \
                 or os.environ.get('DCLR_CLOUD_FUSED', '1') == '0':
             return None
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and (
@@ -697,8 +838,8 @@ class DeepCLR(BaseModel):
         it for each of its side streams when it sees the first batch, so that no launch inside a timed window pays it."""
         sa = self._cloud_layers[0]
         sa0 = getattr(sa, '_sa0', None)
-        if sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda or x.shape[0] % 2 \
-                or x.shape[2] != self._input_dim or os.environ.get('DCLR_CLOUD_FUSED', '1') == '0':
+        if not self._rows_path or sa0 is None or getattr(sa, '_sa1', None) is not None or not sa0.fused or not x.is_cuda \
+                or x.shape[0] % 2 or x.shape[2] != self._input_dim or os.environ.get('DCLR_CLOUD_FUSED', '1') == '0':
             return False
         per, nb, _ = view if view is not None else (x.shape[0] // 2, 1, 0)
         plan = self._cloud_plan(sa0, x, per, nb)
@@ -761,7 +902,7 @@ class DeepCLR(BaseModel):
     def _merge_plan(self, f_rows: torch.Tensor, pairs: int):
         flow, head = self._merge_layers[0], self._merge_layers[1]
         if os.environ.get('DCLR_MERGE_FUSED', '1') == '0' or not isinstance(flow, MotionEmbedding) \
-                or not isinstance(head, OutputSimple):
+                or not isinstance(head, OutputSimple) or not self._rows_path:
             return None
         # the workspace belongs to one stream: calls enqueued on different streams may run side by side
         key = (f_rows.device, pairs, self.npoint, ops.PRECISION, lib.stream_ptr())
@@ -801,6 +942,8 @@ class DeepCLR(BaseModel):
         """(2B, N, C) -> (2B, 3 + feat, npoint) in the reference's channel-major layout."""
         if m is not None:
             self._augment(x, m)
+        if not self._rows_path:                       # reference: x.transpose(1, 2) -> cloud layers (deepclr.py:516-520)
+            return self._cloud_layers[0](x.transpose(1, 2).contiguous())
         rows = self.cloud_feature_rows(x.contiguous())
         return ops.rows_to_channels(rows, x.shape[0], self.npoint, self._cloud_layers[0].output_dim() - 3)
 
@@ -810,13 +953,19 @@ class DeepCLR(BaseModel):
         if x.shape[0] % 2 != 0:
             raise RuntimeError("batch must hold templates followed by the same number of sources")
         pairs = x.shape[0] // 2
-        if is_feat:
-            f_rows = ops.channels_to_rows(x.contiguous(), ops.F_STRIDE)
+        f_rows = None
+        if not self._rows_path:
+            # module by module in the reference's channel layout (deepclr.py:494-499), each module on the HIP operators
+            feat = x if is_feat else self.cloud_features(x, m)
+            y_pred = self._merge_layers[1](self._merge_layers[0](feat))
         else:
-            if m is not None:
-                self._augment(x, m)
-            f_rows = self.cloud_feature_rows(x.contiguous())
-        y_pred = self.merge_rows(f_rows, pairs)
+            if is_feat:
+                f_rows = ops.channels_to_rows(x.contiguous(), ops.F_STRIDE)
+            else:
+                if m is not None:
+                    self._augment(x, m)
+                f_rows = self.cloud_feature_rows(x.contiguous())
+            y_pred = self.merge_rows(f_rows, pairs)
         if self._loss_layer is None or y is None:
             return y_pred, None, None
         # loss value as the reference returns it (deepclr.py:500-503); debug carries the (augmented, set-abstracted)
@@ -824,6 +973,7 @@ class DeepCLR(BaseModel):
         loss = self._loss_layer(y_pred, y)
         aux = None
         if debug:
-            feat = self._cloud_layers[0].output_dim() - 3
-            aux = {'x_aug': x if is_feat else ops.rows_to_channels(f_rows, x.shape[0], self.npoint, feat)}
+            nfeat = self._cloud_layers[0].output_dim() - 3
+            aux = {'x_aug': x if is_feat else (feat if f_rows is None else
+                                               ops.rows_to_channels(f_rows, x.shape[0], self.npoint, nfeat))}
         return y_pred, loss, aux

@@ -160,7 +160,7 @@ def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
                 shapes[base + '.bias'] = (chans[j + 1],)
             sa_out += spec[-1]
     me = prm['merge']['params']
-    chans = [3 + 2 * sa_out, *me['mlp']]
+    chans = [3 + (2 if me.get('append_features', True) else 1) * sa_out, *me['mlp']]
     for j in range(len(me['mlp'])):
         base = '_merge_layers.0._embedding._conv._sequential.{}._sequential.0'.format(j)
         shapes[base + '.weight'] = (chans[j + 1], chans[j], 1)

@@ -31,7 +31,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+sys.path.insert(0, os.path.dirname(HERE))
 import oracle                                    # noqa: E402
+import helpers                                   # noqa: E402  (tests/helpers.py: configurations shared with the tests)
 from oracle import labels as olabels             # noqa: E402
 from deepclr_amd import synthetic                # noqa: E402
 
@@ -182,6 +184,9 @@ CASES = [
      lambda: synthetic.make_batch('modelnet', 1, 1024), 14, False),
     ('small_global_n256_b2', small_global_cfg, lambda: synthetic.make_batch('kitti', 2, 256, first_pair=7), 15, True),
     ('small_two_level_n512_b2', small_two_level_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=9), 16, True),
+    # configurations no shipped model uses (other widths, k = 40, extra input features, append_features = False)
+    ('custom_widths_n512_b2', helpers.custom_widths_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=17), 17, True),
+    ('custom_features_n384_b2', helpers.custom_features_cfg, helpers.custom_features_batch, 18, True),
 ]
 
 
@@ -240,7 +245,7 @@ def run_case(ref, name, cfg, x_np, wseed, full):
         'y': y_ref.numpy(), 'mat': mats_ref, **extra,
     }
     if full:
-        out.update(bq0=bq[0].numpy().astype(np.int16), bq1=bq[1].numpy().astype(np.int16),
+        out.update(**{'bq%d' % i: t.numpy().astype(np.int16) for i, t in enumerate(bq)},
                    knn=knn_local.numpy().astype(np.int16),
                    cloud_features=feat_ref.numpy(), flow_embedding=emb_ref.numpy())
     else:

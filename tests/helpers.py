@@ -17,6 +17,10 @@ GOLDEN_CASES = {
     'modelnet_n1024_b1': ('modelnet', False),
     'small_global_n256_b2': ('small_global', True),      # k == 0: GlobalGrouping
     'small_two_level_n512_b2': ('small_two_level', True),   # second set-abstraction level (deepclr.py:72-83)
+    # configurations no shipped model uses: other layer widths, k = 40, more input features, append_features = False
+    # (reference deepclr.py:50-70,180-199 accept them; here they run composed from the level-1 HIP operators)
+    'custom_widths_n512_b2': ('custom_widths', True),
+    'custom_features_n384_b2': ('custom_features', True),
 }
 
 
@@ -44,8 +48,41 @@ def small_two_level_cfg() -> dict:
     return cfg
 
 
+def custom_widths_cfg() -> dict:
+    """One scale of widths [32, 32, 64] at level 0, flow MLP [64, 64, 128] over k = 40 neighbours, head 128-128-256 /
+    256-128-64."""
+    cfg = small_cfg()
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'], sa['mlps'] = [128], [[3.0]], [[16]], [[[32, 32, 64]]]
+    cfg['params']['merge']['params'].update(k=40, radius=6.0, mlp=[64, 64, 128])
+    cfg['params']['output']['params'].update(mlp=[128, 128, 256], linear=[256, 128, 64])
+    return cfg
+
+
+def custom_features_cfg() -> dict:
+    """Six input columns (xyz + 3 features), two scales of different depth (80 output features), feature DIFFERENCES in the
+    flow embedding (append_features = False), no radius mask, 96 centroids (not a multiple of 64)."""
+    cfg = small_cfg()
+    cfg['input_dim'] = 6
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'], sa['mlps'] = [96], [[2.0, 4.0]], [[8, 16]], [[[16, 32], [16, 16, 48]]]
+    cfg['params']['merge']['params'].update(k=12, radius=0.0, mlp=[96, 64], append_features=False)
+    cfg['params']['output']['params'].update(mlp=[64, 128], linear=[128, 32])
+    return cfg
+
+
+def custom_features_batch(n_pairs: int = 2, n_points: int = 384) -> np.ndarray:
+    x = synthetic.make_batch('kitti', n_pairs, n_points, first_pair=21)
+    extra = np.random.default_rng(33).uniform(-1.0, 1.0, size=x.shape[:2] + (2,)).astype(np.float32)
+    return np.concatenate((x, extra), axis=2)
+
+
 def case_cfg(name: str) -> dict:
     kind = GOLDEN_CASES[name][0]
+    if kind == 'custom_widths':
+        return custom_widths_cfg()
+    if kind == 'custom_features':
+        return custom_features_cfg()
     if kind == 'small_global':
         return small_global_cfg()
     if kind == 'small_two_level':

@@ -1050,3 +1050,29 @@ def test_cloud_forward_one_call_equals_the_separate_launches(kind, pairs, n, bat
         for i in range(batches):                                         # and every batch against its own plain forward
             yi, _, _ = model(xs[i])
             assert torch.equal(y[i * pairs:(i + 1) * pairs], yi)
+
+
+@pytest.mark.parametrize('k, append', [(0, True), (64, False), (5, True)])
+def test_composed_flow_embedding_variants_against_oracle(k, append):
+    """Shapes beyond the goldens on the composed path: GlobalGrouping (k == 0) with other widths (the neighbourhood rows
+    are processed in chunks), the largest k the search keeps, and a k that pads 59 of 64 rows per neighbourhood; against
+    the CPU oracle, whose composition is pinned by the reference-generated goldens."""
+    from helpers import custom_widths_cfg
+    cfg = custom_widths_cfg()
+    cfg['params']['merge']['params'].update(k=k, append_features=append, radius=5.0 if k else 8.0)
+    sd = synthetic.random_state_dict(cfg, seed=21)
+    model, orc = _models(cfg, sd)
+    assert not model._rows_path
+    x = torch.from_numpy(synthetic.make_batch('kitti', 2, 700, first_pair=31))
+    with torch.no_grad():
+        feat = model.cloud_features(x.to(DEV))
+        y, _, _ = model(x.to(DEV))
+    feat_o = orc.cloud_features(x)
+    _close(feat, feat_o, stage='composed k=%d: cloud_features vs oracle' % k)
+    _close(model._merge_layers[0](feat), orc.flow_embedding(feat_o), stage='composed k=%d: flow_embedding vs oracle' % k)
+    _close(y, orc(x), stage='composed k=%d: y vs oracle' % k)
+    helper = ModelInferenceHelper(model, is_sequential=True)              # the sequential cache works in channel layout too
+    with torch.no_grad():
+        assert helper.predict(x[0].to(DEV)) is None
+        y_seq = helper.predict(x[2].to(DEV))
+    _close(y_seq, orc(x[[0, 2]])[0], stage='composed k=%d: sequential helper vs oracle' % k)

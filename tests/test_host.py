@@ -69,9 +69,7 @@ def test_load_model_config_and_trained_model(tmp_path):
 def test_unsupported_configurations_fail_loudly():
     base = synthetic.model_cfg('kitti')
     for mutate in (lambda c: c['params'].update(batch_norm=True),
-                   lambda c: c['params']['merge']['params'].update(k=40),
-                   lambda c: c['params']['merge']['params'].update(mlp=[64, 64, 128]),
-                   lambda c: c['params']['cloud_features']['params'].update(mlps=[[[32, 32, 64], [16, 16, 32]]])):
+                   lambda c: c['params']['merge']['params'].update(k=65)):      # the kNN search keeps <= 64 neighbours
         cfg = synthetic.model_cfg('kitti')
         mutate(cfg)
         with pytest.raises(NotImplementedError):
@@ -80,6 +78,36 @@ def test_unsupported_configurations_fail_loudly():
     cfg = synthetic.model_cfg('kitti')
     cfg['params']['merge']['params'].update(k=0)                  # GlobalGrouping (deepclr.py:186-187) is supported
     assert build_model(model_config_from_dict(cfg)) is not None
+
+
+def test_configurations_beyond_the_fused_shapes_build_and_take_the_composed_path():
+    """Other layer widths / k up to 64 / more input features / append_features = False (reference deepclr.py:50-70,
+    180-199 accept any): the model builds with the reference's state_dict layout and marks itself for the module-by-module
+    path; its row-pipeline entry points say so instead of computing something else."""
+    from helpers import custom_features_cfg, custom_widths_cfg
+    assert build_model(model_config_from_dict(synthetic.model_cfg('kitti')))._rows_path
+    for factory, keys in ((custom_widths_cfg, {'_merge_layers.0._embedding._conv._sequential.0._sequential.0.weight': (64, 131, 1),
+                                               '_cloud_layers.0._sa0.mlps.0.layer2.conv.weight': (64, 32, 1, 1)}),
+                          (custom_features_cfg, {'_merge_layers.0._embedding._conv._sequential.0._sequential.0.weight': (96, 83, 1),
+                                                 '_cloud_layers.0._sa0.mlps.1.layer0.conv.weight': (16, 6, 1, 1),
+                                                 '_merge_layers.1.conv._sequential.0._sequential.0.weight': (64, 67, 1)})):
+        cfg = factory()
+        model = build_model(model_config_from_dict(cfg))
+        sd = synthetic.random_state_dict(cfg, seed=2)
+        for key, shape in keys.items():
+            assert tuple(sd[key].shape) == shape
+        model.load_state_dict(sd, strict=True)
+        assert not model._rows_path
+        with pytest.raises(NotImplementedError, match='composed'):
+            model._cloud_layers[0].forward_rows(torch.zeros(2, 64, cfg['input_dim']))
+        with pytest.raises(NotImplementedError, match='composed'):
+            model._merge_layers[0].forward_rows(torch.zeros(128, 68), 1, 64)
+    for mutate in (lambda c: c['params']['merge']['params'].update(k=40),
+                   lambda c: c['params']['merge']['params'].update(mlp=[64, 64, 128]),
+                   lambda c: c['params']['cloud_features']['params'].update(mlps=[[[32, 32, 64], [16, 16, 32]]])):
+        cfg = synthetic.model_cfg('kitti')
+        mutate(cfg)
+        assert not build_model(model_config_from_dict(cfg))._rows_path
 
 
 def test_second_set_abstraction_level_builds_with_the_reference_key_layout():
