@@ -1076,3 +1076,109 @@ def test_composed_flow_embedding_variants_against_oracle(k, append):
         assert helper.predict(x[0].to(DEV)) is None
         y_seq = helper.predict(x[2].to(DEV))
     _close(y_seq, orc(x[[0, 2]])[0], stage='composed k=%d: sequential helper vs oracle' % k)
+
+
+@pytest.mark.parametrize('sequential', [False, True])
+def test_inference_script_call_sequence_runs_on_the_hip_path(tmp_path, sequential):
+    """The body of the reference's scripts/inference.py (lines 29-121), statement for statement, against this package under
+    the reference's import names: load_scenario -> load_model_config -> load_trained_model -> model.cuda() ->
+    ModelInferenceHelper / Evaluator -> scenario.yaml -> per data file: create_input_dataflow -> per pair: predict between
+    two events -> label_type.to_matrix -> evaluator.add_transforms -> evaluator.write; then the result files are read back
+    and compared with the oracle's poses for the same pairs. The data file is a .npz sequence (the reference's LMDB reader
+    is the one piece of the script this build does not provide)."""
+    import yaml
+    from deepclr.config import load_model_config
+    from deepclr.data import create_input_dataflow
+    from deepclr.evaluation import load_scenario, Evaluator
+    from deepclr.models import load_trained_model, ModelInferenceHelper as RefHelper
+    from deepclr.utils.logging import create_logger
+    # -- what the user has on disk: a model directory, a sequence file, a scenario
+    cfg_d = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg_d, seed=3)
+    model_dir = tmp_path / 'models' / 'demo'
+    model_dir.mkdir(parents=True)
+    (model_dir / 'model_config.yaml').write_text(yaml.safe_dump(cfg_d))
+    torch.save(sd, model_dir / 'weights.tar')
+    frames, n = 5, 2048
+    rng = np.random.default_rng(77)
+    clouds = [synthetic.kitti_like_pair(500, n)[0]]
+    poses = [np.eye(4)]
+    for i in range(1, frames):                                           # each frame = the previous one moved a little + noise
+        t, s, m = synthetic.kitti_like_pair(500 + i, n)
+        step = m
+        moved = clouds[-1].copy()
+        moved[:, :3] = (clouds[-1][:, :3] - step[:3, 3]) @ step[:3, :3] + rng.normal(0, 0.01, size=(n, 3))
+        clouds.append(moved.astype(np.float32))
+        poses.append(poses[-1] @ step)
+    seq_file = tmp_path / 'kitti_demo.npz'
+    np.savez(seq_file, clouds=np.stack(clouds), poses=np.stack(poses), timestamps=0.1 * np.arange(frames))
+    scenario = tmp_path / 'scenario.yaml'
+    scenario.write_text(yaml.safe_dump({'name': 'demo', 'dataset_type': 'KITTI_ODOMETRY_VELODYNE', 'sequential': sequential,
+                                        'data': {'seq_a': str(seq_file)}}))
+
+    # -- scripts/inference.py:29-121
+    logger = create_logger('evaluation')
+    scene_cfg = load_scenario(str(scenario), with_method=False)
+    model_path = os.path.join(str(tmp_path / 'models'), 'demo')
+    model_file = os.path.join(model_path, 'model_config.yaml')
+    weights_file = os.path.join(model_path, 'weights.tar')
+    model_cfg = load_model_config(model_file, weights_file)
+    model = load_trained_model(model_cfg)
+    model = model.cuda()
+    helper = RefHelper(model, is_sequential=scene_cfg.sequential)
+    evaluator = Evaluator()
+    output_dir = os.path.join(str(tmp_path / 'out'), 'stamp_{}_{}'.format(scene_cfg.name, model_cfg.model_type.name))
+    os.makedirs(output_dir, exist_ok=True)
+    eval_cfg = scene_cfg.copy()
+    eval_cfg.method.name = model_cfg.model_type.name
+    eval_cfg.method.params.model_name = 'demo'
+    eval_cfg.method.params.model_file = model_file
+    eval_cfg.method.params.weights_file = weights_file
+    eval_cfg.write_file(os.path.join(output_dir, 'scenario.yaml'), invalid=True, internal=True)
+    kept = []
+    for data_name, data_file in scene_cfg.data.items():
+        logger.info("Evaluate '{}'".format(data_file))
+        df = create_input_dataflow(scene_cfg.dataset_type, data_file, shuffle=False)
+        df.reset_state()
+        helper.reset_state()
+        for i, ds in enumerate(df):
+            template = torch.from_numpy(ds['clouds'][0]).cuda()
+            source = torch.from_numpy(ds['clouds'][1]).cuda()
+            stamp = ds['timestamps'][0]
+            transform_gt = ds['transform']
+            t_start = torch.cuda.Event(enable_timing=True)
+            t_end = torch.cuda.Event(enable_timing=True)
+            t_start.record()
+            if scene_cfg.sequential:
+                if not helper.has_state():
+                    helper.predict(template)
+                y_pred = helper.predict(source)
+            else:
+                y_pred = helper.predict(source, template)
+            t_end.record()
+            torch.cuda.synchronize()
+            t_pred = t_start.elapsed_time(t_end)
+            if y_pred is not None:
+                y_pred = y_pred.detach().cpu().numpy()
+                transform_pred = model_cfg.label_type.to_matrix(y_pred)
+            else:
+                transform_pred = None
+            evaluator.add_transforms(data_name, stamp, transform_pred, transform_gt, t_pred)
+            kept.append((ds['clouds'][0], ds['clouds'][1], transform_gt))
+        assert len(df) == frames - 1 and i == frames - 2
+        del df
+    evaluator.write(output_dir)
+
+    # -- the result files read back (26 columns: stamp, pred 3x4, gt 3x4, ms) against the oracle on the same pairs
+    again = Evaluator.read(output_dir)
+    assert again.has_sequence('seq_a') and os.path.exists(os.path.join(output_dir, 'scenario.yaml'))
+    seq = again.get_sequence('seq_a')
+    table = seq.table()
+    assert table.shape == (frames - 1, 26) and np.allclose(table[:, 0], 0.1 * np.arange(frames - 1)) and (table[:, 25] > 0).all()
+    orc = oracle.build_oracle_model(cfg_d, sd)
+    for row, (t, s, gt) in zip(table, kept):
+        want = olabels.dual_quat_to_matrix(orc(torch.from_numpy(np.stack([t, s])))[0].numpy())
+        assert np.abs(row[1:13].reshape(3, 4) - want[:3]).max() < 1e-4
+        assert np.abs(row[13:25].reshape(3, 4) - gt[:3]).max() < 1e-6
+    stored = yaml.safe_load(open(os.path.join(output_dir, 'scenario.yaml')))
+    assert stored['method']['name'] == 'DEEPCLR' and stored['method']['params']['weights_file'] == weights_file

@@ -325,3 +325,39 @@ def test_hot_kernels_do_not_spill():
     assert not spilled, spilled
     sampler = [v for k, v in usage.items() if 'fps_pruned_kernelILi1024ELi16ELi4ELi3E' in k]      # the table mode (default)
     assert sampler and sampler[0]['vgprs'] <= 128 and sampler[0]['occupancy'] >= 4      # 16 waves = one cloud per CU
+
+
+def test_array_backed_input_dataflow_yields_the_reference_structure(tmp_path):
+    """create_input_dataflow over .npz files: the unified data-point structure of the reference
+    (data/datasets/build.py:97-130), pairs of consecutive frames with transform = inv(pose_i) pose_{i+1}."""
+    from deepclr.data import create_input_dataflow
+    from deepclr.data import DatasetType
+    rng = np.random.default_rng(0)
+    clouds = rng.normal(size=(4, 50, 4))                                   # float64 on disk -> float32 out (ToFloat32)
+    poses = np.tile(np.eye(4), (4, 1, 1))
+    for i in range(4):
+        poses[i, 0, 3] = 1.5 * i
+        poses[i, :2, :2] = [[np.cos(0.1 * i), -np.sin(0.1 * i)], [np.sin(0.1 * i), np.cos(0.1 * i)]]
+    seq = tmp_path / 'seq_07.npz'
+    np.savez(seq, clouds=clouds, poses=poses, timestamps=np.array([0.0, 0.1, 0.2, 0.3]))
+    df = create_input_dataflow(DatasetType.KITTI_ODOMETRY_VELODYNE, str(seq), shuffle=False)
+    df.reset_state()
+    items = list(df)
+    assert len(df) == 3 and len(items) == 3
+    for i, d in enumerate(items):
+        assert sorted(d) == ['augmentations', 'clouds', 'dataset', 'idx', 'timestamps', 'transform']
+        assert d['dataset'] == 'seq_07' and d['idx'] == [i, i + 1] and d['augmentations'] == [None, None]
+        assert d['timestamps'] == [pytest.approx(0.1 * i), pytest.approx(0.1 * (i + 1))]
+        assert d['clouds'][0].dtype == np.float32 and np.array_equal(d['clouds'][1], clouds[i + 1].astype(np.float32))
+        np.testing.assert_allclose(d['transform'], np.linalg.inv(poses[i]).dot(poses[i + 1]), atol=1e-6)
+    pairs = tmp_path / 'pairs.npz'
+    np.savez(pairs, templates=clouds[:2], sources=clouds[2:], transforms=poses[:2])
+    items = list(create_input_dataflow(DatasetType.GENERIC, str(pairs)))
+    assert len(items) == 2 and np.array_equal(items[1]['clouds'][1], clouds[3].astype(np.float32))
+    objs = tmp_path / 'objects.npz'
+    np.savez(objs, clouds=clouds[:, :, :3])
+    items = list(create_input_dataflow(DatasetType.MODELNET40, str(objs)))
+    assert len(items) == 4 and np.array_equal(items[2]['clouds'][0], items[2]['clouds'][1]) \
+        and items[2]['clouds'][0] is not items[2]['clouds'][1] and np.array_equal(items[2]['transform'], np.eye(4))
+    with pytest.raises(RuntimeError, match='LMDB'):
+        create_input_dataflow(DatasetType.GENERIC, str(tmp_path / 'data.lmdb'))
