@@ -102,6 +102,28 @@ def rank_environments(n: int, port: int, base_env=None):
     return envs
 
 
+def rank_cores(local_rank: int, local_world: int, available=None):
+    """The host cores of one rank: the cores this process may run on, dealt in contiguous, disjoint slices to the ranks of
+    the node (8 ranks share one host: eight Python host loops, their HIP runtime threads and RCCL's proxy threads otherwise
+    migrate over -- and contend for -- the same cores). Fewer cores than ranks: no pinning (None)."""
+    cores = sorted(os.sched_getaffinity(0) if available is None else available)
+    if local_world <= 1 or len(cores) < local_world:
+        return None
+    per = len(cores) // local_world
+    return cores[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank(local_rank: int, local_world: int):
+    """Pin this process (and the threads it starts later) to its slice; DCLR_BENCH_PIN=0 leaves the affinity alone."""
+    if os.environ.get('DCLR_BENCH_PIN', '1') == '0':
+        return None
+    cores = rank_cores(local_rank, local_world)
+    if cores:
+        os.sched_setaffinity(0, cores)
+        torch.set_num_threads(max(1, min(len(cores), torch.get_num_threads())))
+    return cores
+
+
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(('127.0.0.1', 0))
@@ -611,6 +633,7 @@ def run(args):
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={}'.format(args.gpus, world))
+    pinned = pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))      # before any worker thread exists
     wl = CONFIGS[args.config]
     kind, pairs_cfg, points = wl['kind'], wl['pairs'], wl['points']
     cloud_kind = 'ring' if args.clouds == 'ring' else kind
@@ -914,12 +937,16 @@ def run(args):
     gather_check = None
     if stub and gather is not None:
         # every rank's block of the last flushed all-gather must hold that rank's values for the steps it covered
-        # (the fence after the warm-up flushes, so slots count from the start of the timed window)
+        # (the fence after the warm-up flushes, so slots count from the start of the timed window) -- checked ON EVERY
+        # RANK (each holds the whole gathered buffer) and agreed on through a MIN all-reduce
         covered = args.steps % gather.every or gather.every
         first = args.warmup + args.steps - covered
         got = gather.gathered.view(world, gather.every, pairs_per_step, -1)
-        gather_check = all(bool((got[r, s] == StubModel.expected(r, first + s)).all())
-                           for r in range(world) for s in range(covered))
+        mine = all(bool((got[r, s] == StubModel.expected(r, first + s)).all())
+                   for r in range(world) for s in range(covered))
+        flag = torch.tensor([1 if mine else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = bool(flag.item())
 
     if rank == 0:
         pairs_total = world * pairs_per_step * args.steps
@@ -1013,6 +1040,8 @@ def run(args):
                                                                 'batches_per_dense_launch':
                                                                 args.group if getattr(runner, '_dense_group', False) else 1}},
             'ranks_seen': ranks_seen,
+            'host_cores_of_rank0': None if not pinned else '{}-{} ({} of the {} this node grants, one disjoint slice per rank)'.format(
+                pinned[0], pinned[-1], len(pinned), len(pinned) * int(os.environ.get('LOCAL_WORLD_SIZE', world))),
             'collectives': None if gather is None else {'all_gathers': gather.collectives, 'steps_per_all_gather': gather.every,
                                                          'bytes_per_rank': int(gather.send.numel() * 4)},
             'roofline': roofline,

@@ -269,3 +269,31 @@ def test_new_arguments_parse(bench):
     a = bench.parse_args(['--same-batch', '--pose-budget', '5'])
     assert a.same_batch and a.pose_budget == 5.0
     assert not bench.parse_args([]).same_batch
+
+
+def test_ranks_get_disjoint_core_slices(bench):
+    """Eight ranks on one host: contiguous, disjoint slices of the cores the process may use; no pinning when the host has
+    fewer cores than ranks or for a single rank."""
+    avail = list(range(4, 68))                                                 # 64 cores, not starting at 0
+    slices = [bench.rank_cores(r, 8, avail) for r in range(8)]
+    assert all(len(sl) == 8 for sl in slices) and slices[0] == list(range(4, 12)) and slices[7] == list(range(60, 68))
+    assert len(set(c for sl in slices for c in sl)) == 64
+    assert bench.rank_cores(0, 1, avail) is None and bench.rank_cores(3, 8, [0, 1, 2]) is None
+    assert bench.rank_cores(1, 3, list(range(8))) == [2, 3]                     # 8 cores over 3 ranks: 2 each, 2 left unassigned
+
+
+def test_eight_rank_launch_with_the_stub_gathers_on_every_rank(bench):
+    """`python bench.py --gpus 8 --cpu-stub`: the self-launcher's eight children over gloo, one all-gather per 4 steps,
+    the gathered buffer verified on EVERY rank (MIN all-reduce of the per-rank verdicts), ranks pinned to disjoint cores
+    where the host has enough of them."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--cpu-stub', '--steps', '12',
+                          '--warmup', '4', '--gather-every', '4'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['ranks_seen'] == list(range(8)) and line['n_gpus'] == 8 and line['gather_check'] is True
+    assert line['collectives']['all_gathers'] == 4 and line['config']['parallelism'] == 'dp8'     # 1 in the warm-up + 3
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert line['host_cores_of_rank0'] is not None

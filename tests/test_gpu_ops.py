@@ -97,6 +97,36 @@ def test_fps_level1_large_cloud_and_temp_side_effect():
         torch.testing.assert_close(temp[0], ref_temp, rtol=1e-5, atol=1e-6)
 
 
+def test_fps_level1_concurrent_streams_with_stream_ordered_scratch():
+    """dclr_furthest_point_sampling allocates its workspace in stream order (hipMallocAsync) for 16384 < n <= 65536 -- the
+    upstream signature has no workspace argument. Two streams calling it at the same time, several times over, must each
+    get the oracle's indices and running minima: their allocations, kernels and frees interleave on the device."""
+    from deepclr_amd import lib
+    m = 96
+    clouds = [_cloud('normal', 2, 20000, 11), _cloud('kitti', 2, 20000, 12)]
+    want = [oracle.furthest_point_sample(c, m) for c in clouds]
+    xs = [c.to(DEV) for c in clouds]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for i, st in enumerate(streams):                      # enqueue on both streams back to back: the launches overlap
+            with torch.cuda.stream(st):
+                temp = torch.full((2, 20000), 1e10, device=DEV)
+                idx = torch.empty(2, m, dtype=torch.int32, device=DEV)
+                lib.check(lib.load().dclr_furthest_point_sampling(2, 20000, m, xs[i].data_ptr(), temp.data_ptr(), idx.data_ptr(),
+                                                                  st.cuda_stream), 'fps')
+                outs[i].append((idx, temp))
+    torch.cuda.synchronize()
+    for i in range(2):
+        sel = xs[i][:, :, None, :]
+        for idx, temp in outs[i]:
+            assert torch.equal(idx.cpu(), want[i])
+            picks = torch.gather(xs[i], 1, idx[:, :-1].long()[:, :, None].expand(-1, -1, 3))          # (2, m-1, 3)
+            ref_temp = ((sel - picks[:, None, :, :]) ** 2).sum(-1).min(dim=2).values
+            torch.testing.assert_close(temp, ref_temp, rtol=1e-5, atol=1e-6)
+
+
 def test_fps_clouds_matches_level1_on_interleaved_input():
     x = torch.from_numpy(synthetic.make_batch('kitti', 1, 3000)).to(DEV)       # (2, 3000, 4)
     a = ops.fps_clouds(x, 333)
