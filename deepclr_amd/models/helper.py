@@ -115,23 +115,37 @@ class LinearMultiLayer(_Stack):
         return x
 
 
+def _structure_stamp(mods) -> int:
+    """Cheap fingerprint of a module tree's SHAPE: registering a parameter or a submodule anywhere in it changes the
+    count it sums (len() of the per-module dicts: no tensor is touched)."""
+    return sum(len(m._parameters) + len(m._modules) for m in mods)
+
+
 def flat_parameters(module: nn.Module):
     """The module's parameters in `parameters()` order without walking the module tree on every call: the (owner dict,
     name) slots are collected once per module and the CURRENT tensor of each slot is fetched from them, so that replaced
     parameters (`m.weight = nn.Parameter(...)`), in-place loads and device moves are all seen. The hot paths ask for the
     weights' versions several times per launch; `parameters()` cost ~0.1 ms each time (23 tensors behind a recursive
     generator) -- 0.4 ms of host time per dense call + sampling chain, exposed whenever the GPU waits for the host
-    (the first launches of a timed window). Submodules added after the first call are not picked up."""
-    slots = module.__dict__.get('_dclr_param_slots')
-    if slots is None:
-        slots, seen = [], set()
-        for m in module.modules():
-            for name, prm in m._parameters.items():
-                if prm is not None and id(prm) not in seen:
-                    seen.add(id(prm))
-                    slots.append((m._parameters, name))
-        module.__dict__['_dclr_param_slots'] = slots
-    return [d[n] for d, n in slots if d.get(n) is not None]
+    (the first launches of a timed window).
+    The slot list belongs to ONE module object and one tree shape: it records the module it was built for and the
+    tree's structure stamp, and is rebuilt when either differs -- a parameter or submodule registered later is picked
+    up, and a replica made by copying `__dict__` (nn.Module._replicate_for_data_parallel, copy.copy) does not key its
+    caches on the original's parameters."""
+    cached = module.__dict__.get('_dclr_param_slots')
+    if cached is None or cached[0] is not module or cached[2] != _structure_stamp(cached[1]):
+        mods = list(module.modules())
+        # every slot, also the ones that hold None now (`register_parameter('bias', None)` filled in later)
+        slots = [(m._parameters, name) for m in mods for name in m._parameters]
+        cached = (module, mods, _structure_stamp(mods), slots)
+        module.__dict__['_dclr_param_slots'] = cached
+    out, seen = [], set()
+    for d, n in cached[3]:
+        prm = d.get(n)
+        if prm is not None and id(prm) not in seen:                # tied weights are listed once, as parameters() does
+            seen.add(id(prm))
+            out.append(prm)
+    return out
 
 
 class PackedCache:

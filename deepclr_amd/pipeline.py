@@ -63,7 +63,6 @@ class PipelinedForward:
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
-        self._ready = {}                            # id(batch) -> event its producer recorded (prefetch(ready=...))
         self.prefetched = 0                         # batches accepted by prefetch() so far (feeders watch this)
 
     def prefetch(self, x: torch.Tensor, flush: bool = True, ready: Optional[torch.cuda.Event] = None) -> None:
@@ -74,7 +73,9 @@ class PipelinedForward:
         self._waiting.append(x)
         self.prefetched += 1
         if ready is not None:
-            self._ready[id(x)] = ready
+            # the event travels WITH the batch object (an attribute, gone when the tensor is): a dictionary keyed by id()
+            # kept entries of batches that were never launched and handed them to whatever tensor reused the id
+            x._dclr_ready = ready
         if flush or (len(self._waiting) >= self.group and not self._hold_launch):
             self._launch()
 
@@ -89,7 +90,7 @@ class PipelinedForward:
         if not self._inputs_ready:
             side.wait_stream(main)                           # the batches (and anything producing them) are ready
         for b in xs:
-            ev = self._ready.pop(id(b), None)
+            ev = b.__dict__.pop('_dclr_ready', None)
             if ev is not None:
                 side.wait_event(ev)
         fused = getattr(self._model, 'cloud_merge_prep', None) if self._ahead == 'knn' else None
@@ -227,7 +228,7 @@ class PipelinedForward:
                 break
             self.prefetch(nxt, flush=False)
         if ready is None:                                    # never sampled ahead: everything runs here, behind its producer
-            ev = self._ready.pop(id(x), None)
+            ev = x.__dict__.pop('_dclr_ready', None)
             if ev is not None:
                 main.wait_event(ev)
         with torch.no_grad():
@@ -355,7 +356,7 @@ class HostBatchFeeder:
         for j in range(k):
             view = dst[j]
             self._queue.append((slot, view))
-            self._runner._ready[id(view)] = ready   # picked up by whichever prefetch() (or step()) takes the batch
+            view._dclr_ready = ready                # picked up by whichever prefetch() (or step()) takes the batch
 
     def fill(self) -> None:
         """Start sampling for as many queued batches as the pipeline holds (call after the first feed()s)."""

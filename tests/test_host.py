@@ -361,3 +361,27 @@ def test_array_backed_input_dataflow_yields_the_reference_structure(tmp_path):
         and items[2]['clouds'][0] is not items[2]['clouds'][1] and np.array_equal(items[2]['transform'], np.eye(4))
     with pytest.raises(RuntimeError, match='LMDB'):
         create_input_dataflow(DatasetType.GENERIC, str(tmp_path / 'data.lmdb'))
+
+
+def test_flat_parameters_follows_late_registrations_and_replicas():
+    """The cached (owner dict, name) slots behind flat_parameters: a parameter or submodule registered after the first
+    call is picked up (the packed-weight caches key on this list), replaced parameters are seen, and a shallow copy of
+    the module does not reuse the original's list."""
+    import copy
+    from deepclr_amd.models.helper import flat_parameters
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU())
+    first = flat_parameters(net)
+    assert [id(p) for p in first] == [id(p) for p in net.parameters()]
+    net[0].extra = torch.nn.Parameter(torch.zeros(2))                      # registered after the first call
+    assert [id(p) for p in flat_parameters(net)] == [id(p) for p in net.parameters()] and len(flat_parameters(net)) == 3
+    net.add_module('tail', torch.nn.Linear(4, 1))                          # a submodule added later
+    assert [id(p) for p in flat_parameters(net)] == [id(p) for p in net.parameters()] and len(flat_parameters(net)) == 5
+    net[0].weight = torch.nn.Parameter(torch.ones(4, 3))                   # replaced in place: same slot, new tensor
+    assert flat_parameters(net)[0] is net[0].weight
+    twin = copy.copy(net)                                                  # __dict__ copied shallowly, as DataParallel replicas are
+    twin._modules = dict(net._modules)
+    twin._modules['0'] = torch.nn.Linear(3, 4)
+    assert flat_parameters(twin)[0] is twin._modules['0'].weight and flat_parameters(net)[0] is net[0].weight
+    shared = torch.nn.Linear(2, 2)
+    tied = torch.nn.Sequential(shared, shared)                             # the same parameters twice: listed once, as parameters() does
+    assert len(flat_parameters(tied)) == 2
