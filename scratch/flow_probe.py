@@ -6,7 +6,7 @@ from deepclr_amd import ops, synthetic
 from deepclr_amd.config import model_config_from_dict
 from deepclr_amd.models import build_model
 dev = 'cuda:0'
-for kind, pairs, npoint in (('kitti', 8, 1024), ('kitti', 32, 1024), ('modelnet', 256, 512)):
+for kind, pairs, npoint in (('kitti', 8, 1024), ('kitti', 80, 1024), ('modelnet', 256, 512)):
     cfg = synthetic.model_cfg(kind)
     model = build_model(model_config_from_dict(cfg)); model.load_state_dict(synthetic.random_state_dict(cfg, 0)); model = model.to(dev).eval()
     flow = model._merge_layers[0]._embedding
