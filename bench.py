@@ -883,6 +883,9 @@ def run(args):
     if args.alone_only:
         # profiling aid (profiles/collect.py): no timed window, only the launches one after another at the launch
         # sizes of the pipelined run -- a rocprofv3 kernel-stats summary of this command backs `alone_us`
+        with torch.no_grad():                    # the first forward is the range-checked one (dense stages twice, once on the
+            model(x)                             # f32 kernels): keep it out of the pass the profiler summarises
+        sync()
         summary, rounds = solo_pass(args.alone_only)
         if rank == 0:
             print(json.dumps({'alone_pass': True, 'config': args.config, 'clouds': args.clouds, 'iterations': args.alone_only,
@@ -996,6 +999,7 @@ def run(args):
                     # matrix-pipe busy fraction of the launch running alone: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x
                     # kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs (a separate --pmc pass, profiles/collect.py)
                     out['mfma_busy'] = None if tr is None else tr.get('mfma_busy')
+                    out['mfma_busy_clock_ghz'] = None if tr is None else tr.get('mfma_pass_clock_ghz')
                 if solo_us is not None:        # CU-time: what the launch costs the chip when it runs alone
                     out['cu_us_per_pair_alone'] = solo_us * min(1.0, _workgroups(name, cfg) / 256.0) / _pairs_in(name)
                 out.update(extra)

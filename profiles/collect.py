@@ -27,9 +27,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# (the f32-matrix-path kernels run once, in the range-checked first forward: they get span names of their own so that their
+# counters are not averaged into the split-f16 kernels' -- a default build times the split-f16 kernels)
 KERNEL_TO_SPAN = [('fps_', 'fps_clouds'), ('sa_msg_kernel', 'sa_msg_fused'), ('knn_rows_kernel', 'knn_rows'),
-                  ('flow16_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding'),
-                  ('head16', 'head_conv_fused'), ('head_fused_kernel', 'head_conv_fused'),
+                  ('flow16_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding_f32'),
+                  ('head16', 'head_conv_fused'), ('head_fused_kernel', 'head_conv_fused_f32'),
                   ('linear_kernel', 'linear_pair'), ('fc_kernel', 'fc')]
 # enough steps for several grouped launches of every kind in steady state (c2: 10 batches per launch, c5: 20), so that
 # the per-kernel averages are those of the contended run bench.py's `avg_us` reports
@@ -72,11 +74,16 @@ def run(cmd, log):
 
 
 def counter_rows(directory: str):
-    """(kernel name, counter name, value) from every *counter_collection.csv below `directory`."""
+    """(kernel name, counter name, value) from every *counter_collection.csv below `directory`; every dispatch also yields
+    the pseudo-counter '_dur_ns' (End_Timestamp - Start_Timestamp) once."""
     for path in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        seen = set()
         with open(path, newline='') as fh:
             for row in csv.DictReader(fh):
                 yield row['Kernel_Name'], row['Counter_Name'], float(row['Counter_Value'])
+                if row['Dispatch_Id'] not in seen and row.get('End_Timestamp'):
+                    seen.add(row['Dispatch_Id'])
+                    yield row['Kernel_Name'], '_dur_ns', float(row['End_Timestamp']) - float(row['Start_Timestamp'])
 
 
 def per_span_average(directory: str, counter: str, calib: bool = False):
@@ -206,12 +213,18 @@ def main():
         run(['rocprofv3', '--kernel-trace', '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', '--output-format', 'csv', '-d', d,
              '--', py, 'bench.py', '--config', cfg, '--alone-only', '6'], os.path.join(out, 'pmc_{}_mfma.log'.format(cfg)))
         busy, active = per_span_average(d, 'SQ_VALU_MFMA_BUSY_CYCLES'), per_span_average(d, 'GRBM_GUI_ACTIVE')
+        dur = per_span_average(d, '_dur_ns')
         for span in busy:
             if span in active and active[span][0] > 0 and busy[span][0] > 0:
                 rec = spans.setdefault(span, {})
                 rec['SQ_VALU_MFMA_BUSY_CYCLES'], rec['GRBM_GUI_ACTIVE'] = busy[span][0], active[span][0]
-                # busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                # busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+                # A fraction of the kernel's CYCLES at the clock the profiled run had (stored beside it: the chip clocks
+                # lower under the counters than in the timed runs; a kernel bound by the fabric keeps its duration).
                 rec['mfma_busy'] = busy[span][0] / (1024.0 * active[span][0] / 8.0)
+                if span in dur and dur[span][0] > 0:
+                    rec['mfma_pass_us'] = dur[span][0] * 1e-3
+                    rec['mfma_pass_clock_ghz'] = active[span][0] / 8.0 / dur[span][0]
         for span, rec in spans.items():
             f, w = rec.get('FETCH_SIZE_KB', 0.0) * 1024, rec.get('WRITE_SIZE_KB', 0.0) * 1024
             rec['bytes_per_launch_raw'] = f + w
