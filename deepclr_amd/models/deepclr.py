@@ -18,11 +18,12 @@ from typing import Any, Dict, List, Optional, Tuple
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import lib, losses, ops
 from ..config import Config
 from ..labels import LabelType
-from ..pointnet2 import PointnetSAModuleMSG
+from ..pointnet2 import PointnetSAModuleMSG, grouping_operation
 from .base import BaseModel
 from .helper import Conv1dMultiLayer, LinearMultiLayer, PackedCache, flat_parameters
 
@@ -103,6 +104,16 @@ class SetAbstraction(DeepCLRModule):
         ch = ops.rows_to_channels(rows, b, self._sa0.npoint, self._sa0.out_features())
         xyz, feat = self._sa1(ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous())
         return ops.channels_to_rows(torch.cat((xyz.transpose(1, 2), feat), dim=1).contiguous(), ops.F_STRIDE)
+
+    def forward_train(self, clouds: torch.Tensor) -> torch.Tensor:
+        """forward() with a gradient: every level composed from the level-1 HIP operators and their HIP backward
+        (gather / group), the shared MLP and the max in torch (PointnetSAModuleMSG._forward_composed, train branch)."""
+        xyz = clouds[:, :3, :].transpose(1, 2).contiguous()
+        feats = clouds[:, 3:, :].contiguous() if clouds.shape[1] > 3 else None
+        for level in (self._sa0, self._sa1):
+            if level is not None:
+                xyz, feats = level._forward_composed(xyz, feats, train=True)
+        return torch.cat((xyz.transpose(1, 2), feats), dim=1).contiguous()
 
     def forward(self, clouds: torch.Tensor, *_args: Any) -> torch.Tensor:
         """(2B, C, N) channel-major clouds -> (2B, 3 + feat, npoint), as the reference module."""
@@ -213,6 +224,42 @@ class MotionEmbeddingBase(nn.Module):
         e_rows = self.forward_rows(f_rows, b, npoint)
         return ops.rows_to_channels(e_rows, b, npoint, 256)
 
+    def forward_train(self, clouds0: torch.Tensor, clouds1: torch.Tensor) -> torch.Tensor:
+        """forward() with a gradient (reference: deepclr.py:201-231 under autograd): the neighbour lists come from the HIP
+        search (indices: nothing to differentiate), the source rows are gathered through GroupingOperation -- dclr_group_points
+        forward, dclr_group_points_grad backward, what the reference's `pts1[group_index]` gets from torch's index kernels --
+        and the shared MLP, the radius mask and the max run in torch, whose autograd has their backward."""
+        b, c, p0 = clouds0.shape
+        p1 = clouds1.shape[2]
+        d, k = self._point_dim, self._k
+        dev = clouds0.device
+        clouds0, clouds1 = clouds0.contiguous(), clouds1.contiguous()
+        if k > 0:
+            xyz0 = clouds0[:, :d, :].detach().transpose(1, 2).contiguous()
+            xyz1 = clouds1[:, :d, :].detach().transpose(1, 2).contiguous()
+            row = torch.empty(b * p0 * k, dtype=torch.int64, device=dev)
+            col = torch.empty(b * p0 * k, dtype=torch.int64, device=dev)
+            ops._call('dclr_knn', 'knn', b, p1, p0, k, xyz1.data_ptr(), xyz0.data_ptr(), row.data_ptr(), col.data_ptr(),
+                      lib.stream_ptr())
+            if bool((col < 0).any()):
+                raise RuntimeError("kNN grouping: a template point has fewer than k = {} source points".format(k))
+            idx = (col.view(b, p0, k) - (torch.arange(b, device=dev) * p1).view(b, 1, 1)).to(torch.int32).contiguous()
+        else:
+            k = p1
+            idx = torch.arange(p1, dtype=torch.int32, device=dev).view(1, 1, p1).expand(b, p0, p1).contiguous()
+        grouped = grouping_operation(clouds1, idx)                                  # (B, C, P0, k), differentiable
+        pos_diff = grouped[:, :d] - clouds0[:, :d, :].unsqueeze(-1)
+        feat_t = clouds0[:, d:, :].unsqueeze(-1)
+        if self._append_features:
+            h = torch.cat((pos_diff, feat_t.expand(-1, -1, -1, k), grouped[:, d:]), dim=1)
+        else:
+            h = torch.cat((pos_diff, grouped[:, d:] - feat_t), dim=1)
+        for w, bias in self._conv.affine_params():
+            h = F.relu(F.conv2d(h, w.unsqueeze(-1), bias))
+        if self._radius > 0.0:
+            h = h.masked_fill((torch.norm(pos_diff, dim=1) >= self._radius).unsqueeze(1), 0.0)
+        return torch.cat((clouds0[:, :d, :], h.max(dim=3)[0]), dim=1).contiguous()
+
     def _packed_composed(self):
         """dclr_linear weights of the composed path. The LAST layer gets one extra input column with weight -1e30: the
         rows of neighbours beyond the radius (and the rows that pad a neighbourhood to a multiple of 64) carry 1 there,
@@ -316,6 +363,10 @@ class MotionEmbedding(DeepCLRModule):
     def forward(self, clouds: torch.Tensor) -> torch.Tensor:
         half = clouds.shape[0] // 2
         return self._embedding(clouds[:half], clouds[half:])
+
+    def forward_train(self, clouds: torch.Tensor) -> torch.Tensor:
+        half = clouds.shape[0] // 2
+        return self._embedding.forward_train(clouds[:half], clouds[half:])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -430,6 +481,24 @@ class OutputSimple(DeepCLRModule):
                 g = ops.linear(h, wp, bias, n, kp, relu=True, colmax_groups=b)
         g = self.linear(g)
         return ops.fc(g, self.output.weight, self.output.bias, act=self._act)
+
+    def forward_train(self, x: torch.Tensor) -> torch.Tensor:
+        """forward() with a gradient (reference: deepclr.py:284-294 under autograd; the output activation is applied out of
+        place, the reference's in-place writes into y give the same values)."""
+        if self.training and any(isinstance(m, nn.Dropout) for m in self.linear._sequential):
+            raise NotImplementedError("dropout_keep < 1 is outside this build (every shipped configuration has dropout: 1.0)")
+        h = x
+        for w, bias in self.conv.affine_params():
+            h = F.relu(F.conv1d(h, w, bias))
+        h = h.max(dim=2)[0]
+        for w, bias in self.linear.affine_params():
+            h = F.relu(F.linear(h, w, bias))
+        y = F.linear(h, self.output.weight, self.output.bias)
+        if self._act == 2:                          # dual quaternion: sigmoid on column 0, tanh on 1..3
+            y = torch.cat((torch.sigmoid(y[:, :1]), torch.tanh(y[:, 1:4]), y[:, 4:]), dim=1)
+        elif self._act == 3:                        # quaternion + translation: sigmoid on column 3, tanh on 4..6
+            y = torch.cat((y[:, :3], torch.sigmoid(y[:, 3:4]), torch.tanh(y[:, 4:])), dim=1)
+        return y
 
     def _packed_plain(self):
         def build():
@@ -954,7 +1023,19 @@ class DeepCLR(BaseModel):
             raise RuntimeError("batch must hold templates followed by the same number of sources")
         pairs = x.shape[0] // 2
         f_rows = None
-        if not self._rows_path:
+        if self.training and torch.is_grad_enabled():
+            # Training step (reference: engine/engines.py:57-84 runs forward with m and y, then loss.backward()): module by
+            # module in the reference's channel layout with a gradient -- sampling / ball query / kNN on the HIP operators
+            # (indices), gather and group through the HIP operators and their HIP backward, MLPs and reductions in torch.
+            # The fused inference kernels have no backward; model.eval() (ModelInferenceHelper does it) selects them.
+            if is_feat:
+                feat = x
+            else:
+                if m is not None:
+                    self._augment(x, m)
+                feat = self._cloud_layers[0].forward_train(x.transpose(1, 2).contiguous())
+            y_pred = self._merge_layers[1].forward_train(self._merge_layers[0].forward_train(feat))
+        elif not self._rows_path:
             # module by module in the reference's channel layout (deepclr.py:494-499), each module on the HIP operators
             feat = x if is_feat else self.cloud_features(x, m)
             y_pred = self._merge_layers[1](self._merge_layers[0](feat))

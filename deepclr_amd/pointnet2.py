@@ -202,7 +202,8 @@ class PointnetSAModuleMSG(nn.Module):
         ch = ops.rows_to_channels(rows, b, self.npoint, self.out_features())
         return ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous()
 
-    def _forward_composed(self, xyz: torch.Tensor, features: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _forward_composed(self, xyz: torch.Tensor, features: Optional[torch.Tensor],
+                          train: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """The reference's own composition (QueryAndGroup + SharedMLP + max_pool2d) on the level-1 HIP operators."""
         xyz = xyz.contiguous()
         b = xyz.shape[0]
@@ -214,8 +215,9 @@ class PointnetSAModuleMSG(nn.Module):
         # Training (/root/reference/deepclr/engine/engines.py:57-84 differentiates through the module): gather / group
         # go through the HIP operators and their HIP backward; the shared MLP and the max then stay in torch, whose
         # autograd has their backward (rocBLAS GEMMs). Inference keeps dclr_linear with the max folded into the last layer.
-        train = torch.is_grad_enabled() and (xyz.requires_grad or (feats is not None and feats.requires_grad)
-                                             or any(p.requires_grad for p in flat_parameters(self)))
+        if train is None:
+            train = torch.is_grad_enabled() and (xyz.requires_grad or (feats is not None and feats.requires_grad)
+                                                 or any(p.requires_grad for p in flat_parameters(self)))
         outs = []
         for radius, nsample, layers, stack in zip(self.radii, self.nsamples, self.packed_mlps() if not train else
                                                   [None] * len(self.radii), self.mlps):

@@ -1182,3 +1182,52 @@ def test_inference_script_call_sequence_runs_on_the_hip_path(tmp_path, sequentia
         assert np.abs(row[13:25].reshape(3, 4) - gt[:3]).max() < 1e-6
     stored = yaml.safe_load(open(os.path.join(output_dir, 'scenario.yaml')))
     assert stored['method']['name'] == 'DEEPCLR' and stored['method']['params']['weights_file'] == weights_file
+
+
+@pytest.mark.parametrize('cfg_name', ['small', 'custom_features'])
+def test_training_step_gradients_match_the_oracle_autograd(cfg_name):
+    """model.train() + forward(x, y=labels) + loss.backward() (the reference's training step, engine/engines.py:57-84):
+    sampling / ball query / kNN on the HIP operators, gather and group through the HIP operators and their HIP backward,
+    MLPs in torch. Loss value and EVERY parameter's gradient against torch autograd over the CPU oracle's functional
+    restatement of the same network (float32 on both sides; the index operators are bit-exact, so both differentiate the
+    same piecewise-linear function)."""
+    from helpers import custom_features_batch, custom_features_cfg
+    if cfg_name == 'small':
+        cfg, x_np = small_cfg(), synthetic.make_batch('kitti', 2, 512, first_pair=41)
+    else:
+        cfg, x_np = custom_features_cfg(), custom_features_batch()
+    cfg['params']['loss'] = {'name': 'TransformLoss', 'params': {'p': 2, 'sx': 1.0, 'sq': 10.0}}
+    sd = synthetic.random_state_dict(cfg, seed=23)
+    model = build_model(model_config_from_dict(cfg))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).train()
+    x = torch.from_numpy(x_np)
+    labels = torch.from_numpy(np.stack([LabelType.POSE3D_DUAL_QUAT.from_matrix(synthetic.kitti_like_pair(41 + i, 16)[2])
+                                        for i in range(2)]).astype(np.float32))
+    y_pred, loss, _ = model(x.to(DEV), y=labels.to(DEV))
+    assert y_pred.requires_grad and loss.requires_grad
+    loss.backward()
+    # oracle: the same state_dict as leaf tensors, the same loss module on its outputs
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    orc = oracle.build_oracle_model(cfg, sd)
+    orc.sd = sd_o
+    y_o = orc.pose_head(orc.flow_embedding(orc.cloud_features(x)))
+    loss_o = model._loss_layer.cpu()(y_o, labels)
+    loss_o.backward()
+    _close(y_pred.detach(), y_o.detach(), stage=cfg_name + ': training forward y vs oracle')
+    assert abs(float(loss.detach()) - float(loss_o.detach())) <= 1e-5 * max(1.0, abs(float(loss_o.detach())))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for key, ref in sd_o.items():
+        got = params[key].grad
+        assert got is not None and ref.grad is not None, key
+        scale = float(ref.grad.abs().max())
+        err = float((got.cpu() - ref.grad).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 2e-4 * max(scale, 1e-6), (key, err, scale)
+    print("training step (%s): loss %.6f, worst gradient error / scale %.2e over %d tensors" % (cfg_name, float(loss.detach()), worst, len(sd_o)))
+    # and eval mode still takes the inference kernels with the same outputs
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        y_eval, _, _ = model(x.to(DEV))
+    _close(y_eval, y_o.detach(), stage=cfg_name + ': eval forward after the training step vs oracle')
