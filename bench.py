@@ -456,6 +456,9 @@ def parse_args(argv=None):
                     help='gauss: SURVEY.md 8(d) Gaussian clouds (headline); ring: LiDAR-density ring scans (KITTI configs)')
     ap.add_argument('--latency', action='store_true',
                     help='one pair per ModelInferenceHelper.predict call (pairwise and sequential), per-pair ms')
+    ap.add_argument('--dense-streams', type=int, default=None,
+                    help='single-batch dense launches (--strict, c4): the dense stages of consecutive batches alternate over '
+                         'this many high-priority streams (1: all on the caller\'s stream; default 1, --strict 4)')
     ap.add_argument('--same-batch', action='store_true',
                     help='feed the SAME resident batch every step (rounds 1-3; scripts/timing.py:27-34 does that too) instead '
                          'of a resident ring of distinct batches: the batches of a grouped launch then alias in memory')
@@ -474,6 +477,14 @@ def parse_args(argv=None):
         if args.group not in (None, 1) or args.dense_group not in (None, 0):
             ap.error('--strict fixes --group 1 --dense-group 0')
         args.group, args.dense_group = 1, 0
+        # one batch per launch: 6 sampling streams and 4 dense streams measured best (on ONE stream the six
+        # dependent dense launches of a batch, 0.25-0.37 ms under contention, set the pace: 30.0k pairs/s at 3 x 1, 34.5k at 6 x 4)
+        if args.depth is None:
+            args.depth = 6
+        if args.dense_streams is None:
+            args.dense_streams = 4
+    if args.dense_streams is None:
+        args.dense_streams = 1
     for key in ('steps', 'warmup', 'depth', 'group', 'dense_group'):
         if getattr(args, key) is None:
             setattr(args, key, wl[key])
@@ -728,6 +739,7 @@ def run(args):
         dense_group = bool(args.dense_group) and args.ahead == 'knn' and args.group > 1
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
                                                                group=args.group, dense_group=dense_group,
+                                                               dense_streams=1 if dense_group else args.dense_streams,
                                                                inputs_ready=True)   # resident and never rewritten, or
                                                                                     # ordered by the feeder's copy events
     if args.h2d:
@@ -1041,6 +1053,7 @@ def run(args):
                        'sampling_batches_ahead': 0 if runner is None else args.depth * args.group,
                        'pipeline': None if runner is None else {'side_streams': args.depth, 'batches_per_sampling_launch':
                                                                 args.group, 'ahead': args.ahead,
+                                                                'dense_streams': len(getattr(runner, '_dense_streams', [])) or 1,
                                                                 'batches_per_dense_launch':
                                                                 args.group if getattr(runner, '_dense_group', False) else 1}},
             'ranks_seen': ranks_seen,

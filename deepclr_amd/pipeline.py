@@ -19,7 +19,7 @@ from .models.deepclr import DeepCLR
 
 class PipelinedForward:
     def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
-                 dense_group: bool = False, inputs_ready: bool = False):
+                 dense_group: bool = False, inputs_ready: bool = False, dense_streams: int = 1):
         """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
         abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
         the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
@@ -38,11 +38,19 @@ class PipelinedForward:
         (resident data, or produced on another stream and already synchronised). By default a sampling launch waits
         for everything enqueued on the caller's stream so far -- the safe assumption that the batch was produced
         there -- which also orders it behind the dense launches of OLDER batches the runner itself put on that
-        stream; with inputs_ready it starts at once."""
+        stream; with inputs_ready it starts at once.
+        dense_streams (single-batch dense launches only, i.e. not with dense_group): the dense stages of consecutive batches
+        alternate over this many high-priority streams of the runner's own instead of queueing on the caller's stream. One
+        batch's dense stages are six dependent launches (flow embedding, clear, head, three fully connected layers), 0.25-
+        0.37 ms under contention for 8 KITTI pairs: on ONE stream that chain, not the sampler, sets the pace of the un-fused
+        regime (bench.py --strict). The caller's stream waits for each batch's outputs (an event), so results are ordered
+        for the caller exactly as before."""
         if dense_group and (ahead != 'knn' or group < 2):
             raise ValueError("dense_group needs ahead='knn' and group > 1")
         if depth < 1:
             raise ValueError("depth must be >= 1")
+        if dense_streams < 1 or (dense_streams > 1 and dense_group):
+            raise ValueError("dense_streams > 1 applies to single-batch dense launches (dense_group=False)")
         if ahead not in ('sample', 'features', 'knn'):
             raise ValueError("ahead must be 'sample', 'features' or 'knn'")
         if group < 1 or (group > 1 and ahead == 'sample'):
@@ -61,6 +69,8 @@ class PipelinedForward:
         self._group_out = None                      # (batches of the running dense group, their outputs)
         self._waiting = []                          # batches collected for the next grouped launch
         self._streams = [torch.cuda.Stream() for _ in range(depth)]
+        self._dense_streams = [torch.cuda.Stream(priority=-1) for _ in range(dense_streams)] if dense_streams > 1 else []
+        self._dense_next = 0
         self._next_stream = 0
         self._pending: Deque[Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]] = deque()
         self.prefetched = 0                         # batches accepted by prefetch() so far (feeders watch this)
@@ -218,11 +228,17 @@ class PipelinedForward:
                 self.prefetch(nxt, flush=False)
             y = y_all[:pairs]
             return y if (out is None or whole) else out.copy_(y)
+        dense_on = main
+        if self._dense_streams:
+            dense_on = self._dense_streams[self._dense_next]
+            self._dense_next = (self._dense_next + 1) % len(self._dense_streams)
+            if not self._inputs_ready or out is not None:
+                dense_on.wait_stream(main)                   # whatever produced the batch / last used `out` on the caller's stream
         if self._pending and self._pending[0][0] is x:
             _, ready, done = self._pending.popleft()
-            main.wait_event(done)
+            dense_on.wait_event(done)
             for t in self._tensors(ready):
-                t.record_stream(main)
+                t.record_stream(dense_on)
         for nxt in upcoming:
             if self.in_flight() >= self.depth * self.group:
                 break
@@ -230,8 +246,8 @@ class PipelinedForward:
         if ready is None:                                    # never sampled ahead: everything runs here, behind its producer
             ev = x.__dict__.pop('_dclr_ready', None)
             if ev is not None:
-                main.wait_event(ev)
-        with torch.no_grad():
+                dense_on.wait_event(ev)
+        with torch.no_grad(), torch.cuda.stream(dense_on):
             prep = None
             if self._ahead == 'knn' and ready is not None:
                 ready, prep = ready
@@ -239,7 +255,13 @@ class PipelinedForward:
                 f_rows = ready
             else:
                 f_rows = self._model.cloud_feature_rows(x, ready)
-            return self._dense(f_rows, x, prep, out)
+            y = self._dense(f_rows, x, prep, out)
+        if dense_on is not main:
+            finished = torch.cuda.Event()
+            finished.record(dense_on)
+            main.wait_event(finished)                        # the caller's stream sees the outputs in step order
+            y.record_stream(main)
+        return y
 
     @staticmethod
     def _tensors(obj):

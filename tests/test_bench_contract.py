@@ -80,7 +80,8 @@ def test_measurement_modes_and_the_whole_groups_rule(bench, capsys):
     """--strict / --h2d / --clouds ring / --latency beside the headline; with dense groups a timed window that is not a
     whole number of groups would credit work it did not do: rejected."""
     args = bench.parse_args(['--strict', '--steps', '7'])
-    assert (args.group, args.dense_group, args.depth, args.steps) == (1, 0, 3, 7)
+    assert (args.group, args.dense_group, args.depth, args.dense_streams, args.steps) == (1, 0, 6, 4, 7)
+    assert bench.parse_args([]).dense_streams == 1 and bench.parse_args(['--strict', '--depth', '3']).depth == 3
     with pytest.raises(SystemExit):
         bench.parse_args(['--strict', '--group', '4'])
     for bad in (['--steps', '25', '--warmup', '5'], ['--config', 'c5', '--steps', '30']):

@@ -547,6 +547,18 @@ def test_pipelined_runner_matches_plain_forward():
         assert len(got) == len(want)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+    # single-batch dense launches alternating over several dense streams (bench.py --strict): same results, in step order on
+    # the caller's stream, also when they are written into a caller's buffer
+    for ahead, streams in (('knn', 2), ('knn', 3), ('features', 2)):
+        runner = PipelinedForward(model, depth=4, ahead=ahead, dense_streams=streams, inputs_ready=True)
+        got = list(runner.run(batches + batches))
+        assert len(got) == 2 * len(want) and all(torch.equal(a, b) for a, b in zip(got, want + want))
+        slots = torch.zeros(len(batches), want[0].shape[0], want[0].shape[1], device=DEV)
+        for i, b in enumerate(batches):
+            runner.step(b, batches[i + 1:], out=slots[i])
+        assert torch.equal(slots, torch.stack(want))
+    with pytest.raises(ValueError):
+        PipelinedForward(model, depth=2, ahead='knn', group=2, dense_group=True, dense_streams=2)
     # dense groups writing straight into a caller's buffer: whole groups at their first step, singles otherwise
     runner = PipelinedForward(model, depth=2, ahead='knn', group=2, dense_group=True)
     slots = torch.zeros(len(batches), want[0].shape[0], want[0].shape[1], device=DEV)
