@@ -105,6 +105,30 @@ def git_commit():
         return os.environ.get('DCLR_COMMIT', 'unknown (no .git on the GPU box)')
 
 
+def run_modes(args, out, py):
+    """The bench lines beside the headline (MODES), each with the rocprofv3 kernel-stats summary of the same command. Run
+    AFTER the PMC passes: profiles/pmc_traffic.json then holds this tree's figures and the lines carry `traffic` / `mfma_busy`."""
+    for mode in [m for m in args.modes.split(',') if m]:
+        extra = MODES[mode]
+        line = os.path.join(out, '{}_bench_{}.json'.format(args.tag, mode))
+        run([py, 'bench.py'] + extra, line)
+        with open(line) as fh:                                 # keep the JSON line only (stderr chatter goes to the log)
+            txt = fh.read()
+        rows = [l for l in txt.splitlines() if l.startswith('{')]
+        with open(line, 'w') as fh:
+            fh.write((rows[-1] if rows else txt) + '\n')
+        if rows:
+            doc_ = json.loads(rows[-1])
+            print(mode, 'value', round(doc_['value'], 1), doc_['unit'], 'ms/step', round(doc_['ms_per_step'], 4),
+                  'pose', doc_.get('pose_delta_vs_oracle'), flush=True)
+        d = os.path.join(out, 'raw_stats_' + mode)
+        run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', py, 'bench.py'] + extra +
+            ['--no-cpu-baseline', '--no-launch-timer'], os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, mode)))
+        for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
+            shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, mode)))
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tag', required=True)
@@ -126,26 +150,8 @@ def main():
         return
     os.makedirs(out, exist_ok=True)
     py = sys.executable
-    for mode in [m for m in args.modes.split(',') if m]:
-        extra = MODES[mode]
-        line = os.path.join(out, '{}_bench_{}.json'.format(args.tag, mode))
-        run([py, 'bench.py'] + extra, line)
-        with open(line) as fh:                                 # keep the JSON line only (stderr chatter goes to the log)
-            txt = fh.read()
-        rows = [l for l in txt.splitlines() if l.startswith('{')]
-        with open(line, 'w') as fh:
-            fh.write((rows[-1] if rows else txt) + '\n')
-        if rows:
-            doc_ = json.loads(rows[-1])
-            print(mode, 'value', round(doc_['value'], 1), doc_['unit'], 'ms/step', round(doc_['ms_per_step'], 4),
-                  'pose', doc_.get('pose_delta_vs_oracle'), flush=True)
-        d = os.path.join(out, 'raw_stats_' + mode)
-        run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', py, 'bench.py'] + extra +
-            ['--no-cpu-baseline', '--no-launch-timer'], os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, mode)))
-        for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
-            shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, mode)))
-        shutil.rmtree(d, ignore_errors=True)
-    if args.modes and args.configs == 'none':
+    if args.configs == 'none':
+        run_modes(args, out, py)
         return
     from bench import kernel_source_hash
     doc = {'_how': __doc__.split('\n\n')[1].replace('\n', ' '), 'commit': git_commit(),
@@ -237,6 +243,8 @@ def main():
         with open(path, 'w') as fh:
             json.dump(doc, fh, indent=1)
         print('wrote', path)
+        shutil.copy(path, os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))      # the lines below attach these figures
+    run_modes(args, out, py)
     for d in glob.glob(os.path.join(out, 'raw_*')):        # keep gpurun_out small: the summaries are what travels
         shutil.rmtree(d, ignore_errors=True)
 
