@@ -768,7 +768,7 @@ def run(args):
     in_place_left = [0]
     stepped = [0]                                # steps taken so far = index (mod the ring) of the next batch
     recent = []                                  # (batch, outputs) of the latest steps: two launch groups for the pose check
-    keep_recent = 2 * args.group if (getattr(runner, '_dense_group', False) and not args.sequence) else 1
+    keep_recent = 1 if args.sequence else 2 * max(1, args.group)
 
     def step():
         # the outputs go straight into the all-gather's send buffer where the runner allows it: one slot per step,
@@ -852,8 +852,11 @@ def run(args):
 
     def latency_pass(n_steps):
         """Untimed pass through the SAME pipeline: per batch, the time from the step in which the runner accepted it
-        (prefetch) to the moment its pose outputs were complete on the device. The host keeps enqueueing as in the timed
-        loop; a watcher thread waits on one event per step (recorded behind that step's outputs) and stamps the clock."""
+        (prefetch) to the moment its pose outputs were complete on the device; a watcher thread waits on one event per step
+        (recorded behind that step's outputs) and stamps the clock. The pass is CLOSED-LOOP: a step is taken only once the
+        outputs of the step `outstanding` = (side streams + 1) x batches per launch earlier are complete -- a client that
+        keeps the pipeline exactly full. (The timed loop is open-loop: the host enqueues hundreds of steps ahead of the GPU,
+        and a batch's wait in that queue is the loop's doing, not the pipeline's.)"""
         import threading
         import queue
         if runner is None or feeder is not None or args.sequence:
@@ -873,7 +876,11 @@ def run(args):
         th.start()
         submitted = {}
         first = stepped[0]
+        outstanding = (args.depth + 1) * args.group
         for _ in range(n_steps):
+            need = stepped[0] - outstanding                   # closed loop: that step's outputs must be out
+            while need >= first and need not in done_at:
+                time.sleep(2e-5)
             before, t = runner.prefetched, time.perf_counter()
             step()
             for seq in range(before, runner.prefetched):
@@ -888,9 +895,10 @@ def run(args):
         if not lat:
             return None
         return {'median': lat[len(lat) // 2], 'p90': lat[int(0.9 * (len(lat) - 1))], 'max': lat[-1], 'min': lat[0],
-                'batches': len(lat),
+                'batches': len(lat), 'outstanding_batches': outstanding,
                 'definition': 'per batch: host time at which the runner accepted it for sampling -> its pose outputs complete '
-                              'on the device (event wait in a watcher thread); untimed pass over the same pipeline'}
+                              'on the device (event wait in a watcher thread); untimed closed-loop pass over the same pipeline '
+                              'with `outstanding_batches` batches in flight'}
 
     if args.alone_only:
         # profiling aid (profiles/collect.py): no timed window, only the launches one after another at the launch
@@ -941,7 +949,7 @@ def run(args):
     recent_kept = list(recent)                   # the last two launch groups of the TIMED loop (pose check below)
     alone, fps_rounds, latency = None, None, None
     if rank == 0 and not stub and world == 1:
-        latency = latency_pass((args.depth + 3) * args.group if args.group > 1 else 4 * args.depth + 8)   # > the batches in flight
+        latency = latency_pass((args.depth + 4) * args.group if args.group > 1 else 5 * args.depth + 10)   # > the batches in flight
     if timer is not None and rank == 0:
         alone, fps_rounds = solo_pass(6)
     if use_dist:
