@@ -31,15 +31,21 @@ __host__ __device__ constexpr int f16_octet_offset(int o) { return 256 * (o & 1)
 
 // One pass over K for T row tiles x 2 channel tiles. TRANSPOSED: weights are the A operand.
 // ABL (timing-only ablations, results wrong): bit 0 = no gather round trips in phase A (rows built from constants),
-// bit 1 = weight fragments always from k-step 0 of tile 0 (no weight streaming), bit 2 = no phase A at all
+// bit 1 = weight fragments always from k-step 0 of tile 0 (no weight streaming), bit 2 = no phase A at all, bit 3 = no weight
+// loads at all (80 pairs: 497 us; ABL 1 / 2 / 8 / 9 / 4 / 12: 465 / 457 / 414 / 385 / 366 / 298)
 template <int T, bool TRANSPOSED, int ABL = 0>
 __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4 (&acc2)[T][2], const char *a_lane,
                                              const float4 *wh_lane, const float4 *wl_lane, int tile_stride) {
     dclr_h8 h0[2], l0[2], h1[2], l1[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride);
-        l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride);
+        if constexpr (ABL & 8) {                                  // timing probe: no weight loads at all
+            h0[u] = __builtin_bit_cast(dclr_h8, make_float4(1.f, 2.f, (float)u, 3.f));
+            l0[u] = h0[u];
+        } else {
+            h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride);
+            l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride);
+        }
     }
     auto step = [&](int g, const dclr_h8 (&wh)[2], const dclr_h8 (&wl)[2]) {
 #pragma unroll
@@ -61,7 +67,7 @@ __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4
     for (int g = 0; g < F16_KG; g += 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if constexpr (ABL & 2) { h1[u] = l0[u]; l1[u] = h0[u]; }
+            if constexpr (ABL & 10) { h1[u] = l0[u]; l1[u] = h0[u]; }
             else {
             h1[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
             l1[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 1) * 64);
@@ -72,7 +78,7 @@ __device__ __forceinline__ void flow16_panel(dclr_f32x4 (&acc)[T][2], dclr_f32x4
         if (g + 2 < F16_KG) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                if constexpr (ABL & 2) { h0[u] = l1[u]; l0[u] = h1[u]; }
+                if constexpr (ABL & 10) { h0[u] = l1[u]; l0[u] = h1[u]; }
                 else {
                 h0[u] = dclr_frag_h8(wh_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
                 l0[u] = dclr_frag_h8(wl_lane + (size_t)u * tile_stride + (size_t)(g + 2) * 64);
@@ -296,7 +302,7 @@ extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float
     static const int abl = getenv("DCLR_FLOW_ABL") ? atoi(getenv("DCLR_FLOW_ABL")) : 0;      // k = 20 only
     if (abl != 0 && (k + 3) / 4 == 5) {
 #define DCLR_FLOW16_ABL(A) case A: flow16_launch<5, A>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
-        switch (abl) { DCLR_FLOW16_ABL(1); DCLR_FLOW16_ABL(2); DCLR_FLOW16_ABL(3); DCLR_FLOW16_ABL(4); DCLR_FLOW16_ABL(6); default: break; }
+        switch (abl) { DCLR_FLOW16_ABL(1); DCLR_FLOW16_ABL(2); DCLR_FLOW16_ABL(3); DCLR_FLOW16_ABL(4); DCLR_FLOW16_ABL(6); DCLR_FLOW16_ABL(8); DCLR_FLOW16_ABL(9); DCLR_FLOW16_ABL(12); default: break; }
 #undef DCLR_FLOW16_ABL
         return dclr_launch_status();
     }
