@@ -898,6 +898,8 @@ class DeepCLR(BaseModel):
             plan = _CloudPlan.build(sa0, merge_plan, x.device, per, nb, x.shape[1], x.shape[2])
             if plan is None:
                 return None
+            if len(self._plans) > 16:                  # many launch shapes: do not hoard their scratch (plans in use stay
+                self._plans.clear()                    # alive through their callers' references)
             self._plans[key] = plan
         return plan
 
