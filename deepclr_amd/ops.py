@@ -17,6 +17,7 @@ from . import lib
 
 F_STRIDE = 68
 E_STRIDE = 264
+FUSED_MAX_POINTS = 65536        # points per cloud the fused sampler / set-abstraction kernels take (16-bit point indices)
 
 # Optional launch timer (bench.py): an object with begin(name) -> token and end(token), called on the
 # stream the kernel is enqueued on. None in normal operation.
@@ -179,6 +180,10 @@ def fps_clouds(clouds: torch.Tensor, npoint: int) -> torch.Tensor:
     workspace variant (sorted points + running minima in a scratch buffer, only ~10 % of it touched per round)."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
+    if n > FUSED_MAX_POINTS:
+        # beyond the fused samplers (65536 points per cloud): the level-1 operator, which takes any n (running minima in
+        # global memory), on a packed copy of the coordinates
+        return furthest_point_sample(clouds[:, :, :3].contiguous(), npoint)
     idx = torch.empty(b, npoint, dtype=torch.int32, device=clouds.device)
     need = lib.load().dclr_fps_workspace_bytes(b, n)
     if need > 0 and npoint * 4 <= 32 * 1024:

@@ -121,6 +121,7 @@ class PointnetSAModuleMSG(nn.Module):
                                                  # gradient is wanted, also for shapes the fused kernel covers
         self.fused = fused                       # one-kernel path (csrc/sa.hip); otherwise level-1 operators + dclr_linear
         self._cache = PackedCache()
+        self._cache_composed = PackedCache()
         self._range_ok = None                    # weights key of the last checked split-f16 pass (ops.CHECK_RANGE)
 
     def out_features(self) -> int:
@@ -129,10 +130,17 @@ class PointnetSAModuleMSG(nn.Module):
     def packed_mlps(self):
         """Fused path: one flat [W1 b1 W2 b2 W3 b3] buffer per scale. Composed path: per scale a list of
         (packed weight, bias, n_out, padded K) for dclr_linear."""
+        if not self.fused:
+            return self.packed_mlps_composed()
+
         def build():
-            if self.fused:
-                return [ops.pack_sa_mlp([u.conv.weight for u in stack], [u.conv.bias for u in stack])
-                        for stack in self.mlps]
+            return [ops.pack_sa_mlp([u.conv.weight for u in stack], [u.conv.bias for u in stack]) for stack in self.mlps]
+        return self._cache.get(flat_parameters(self), build)
+
+    def packed_mlps_composed(self):
+        """Per scale a list of (packed weight, bias, n_out, padded K) for dclr_linear: the composed path's weights (the
+        composed path also serves fused-shape modules on clouds beyond the fused kernels' 65536 points)."""
+        def build():
             packed = []
             for stack in self.mlps:
                 layers = []
@@ -142,7 +150,7 @@ class PointnetSAModuleMSG(nn.Module):
                     layers.append((ops.pack_weight(w, kp), u.conv.bias.detach().contiguous(), w.shape[0], kp))
                 packed.append(layers)
             return packed
-        return self._cache.get(flat_parameters(self), build)
+        return self._cache_composed.get(flat_parameters(self), build)
 
     def sample(self, clouds: torch.Tensor, view=None):
         """Furthest point sampling only (the serial stage; the pipelined runner issues it batches ahead
@@ -164,6 +172,15 @@ class PointnetSAModuleMSG(nn.Module):
 
     def forward_rows(self, clouds: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """clouds (B, N, 3 + in_feat) interleaved -> feature rows F (B*npoint, 68); sample = self.sample(clouds)."""
+        if clouds.shape[1] > ops.FUSED_MAX_POINTS:
+            # more points per cloud than the fused kernels index (16 bits): the same module composed from the level-1
+            # operators, which take any n; rows F from its channel-layout result
+            if view is not None:
+                raise RuntimeError("clouds of more than {} points are not read in place across batches".format(ops.FUSED_MAX_POINTS))
+            xyz = clouds[:, :, :3].contiguous()
+            feats = clouds[:, :, 3:].transpose(1, 2).contiguous() if clouds.shape[2] > 3 else None
+            new_xyz, new_feats = self._forward_composed(xyz, feats, train=False)
+            return ops.channels_to_rows(torch.cat((new_xyz.transpose(1, 2), new_feats), dim=1).contiguous(), ops.F_STRIDE)
         if sample is None:
             sample = self.sample(clouds, view)
         idx, gpts, gbox = sample[:3]
@@ -219,7 +236,7 @@ class PointnetSAModuleMSG(nn.Module):
             train = torch.is_grad_enabled() and (xyz.requires_grad or (feats is not None and feats.requires_grad)
                                                  or any(p.requires_grad for p in flat_parameters(self)))
         outs = []
-        for radius, nsample, layers, stack in zip(self.radii, self.nsamples, self.packed_mlps() if not train else
+        for radius, nsample, layers, stack in zip(self.radii, self.nsamples, self.packed_mlps_composed() if not train else
                                                   [None] * len(self.radii), self.mlps):
             bq = ops.ball_query(radius, nsample, xyz.detach(), new_xyz.detach())   # (B, npoint, nsample) int32
             if train:

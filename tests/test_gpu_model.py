@@ -1243,3 +1243,22 @@ def test_training_step_gradients_match_the_oracle_autograd(cfg_name):
     with torch.no_grad():
         y_eval, _, _ = model(x.to(DEV))
     _close(y_eval, y_o.detach(), stage=cfg_name + ': eval forward after the training step vs oracle')
+
+
+def test_clouds_beyond_the_fused_kernels_point_limit_run_composed():
+    """More than 65536 points per cloud (the fused sampler and set-abstraction kernels index points with 16 bits; a raw
+    KITTI scan holds ~120k): the same module composed from the level-1 operators, which take any n -- results against the
+    oracle as for every other size, through forward(), cloud_features() and the inference helper."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=6)
+    model, orc = _models(cfg, sd)
+    x = torch.from_numpy(synthetic.make_batch('kitti', 1, 70001, first_pair=3))
+    with torch.no_grad():
+        feat = model.cloud_features(x.to(DEV))
+        y, _, _ = model(x.to(DEV))
+        y_h = ModelInferenceHelper(model).predict(x[1].to(DEV), x[0].to(DEV))
+    feat_o = orc.cloud_features(x)
+    assert torch.equal(feat[:, :3].cpu(), feat_o[:, :3])                   # the same 1024 centroids
+    _close(feat, feat_o, stage='70001 points: cloud_features vs oracle')
+    _close(y, orc(x), stage='70001 points: y vs oracle')
+    assert torch.equal(y_h, y[0])
