@@ -44,6 +44,10 @@ CASES = {
     'modelnet_n4096_m128': ('modelnet', 4096, 128, 8),
     'sheet_n4096_m512':    ('sheet', 4096, 512, 9),
     'few_points_n96_m200': ('normal', 96, 200, 10),     # n >= points: the transform returns the cloud as it is
+    # round 5: the sizes the headline kernels run at. fps_pruned_kernel<1024,16,4,3> takes N = 16384 (the c2 sampler),
+    # fps_paged_kernel every 16384 < N <= 65536 (the reference's float64 distance matrix of N = 20000 is 3.2 GB)
+    'kitti_n16384_m1024':  ('kitti', 16384, 1024, 11),
+    'kitti_n20000_m256':   ('kitti', 20000, 256, 12),
 }
 
 

@@ -48,7 +48,7 @@ def test_oracle_reproduces_golden(name):
 def _fps_reference_cases(golden_dir):
     g = np.load(os.path.join(golden_dir, 'fps_reference.npz'))
     names = sorted({k.split('/')[0] for k in g.files})
-    assert len(names) >= 6
+    assert len(names) >= 6 and {'kitti_n16384_m1024', 'kitti_n20000_m256'} <= set(names)
     return [(n, g[n + '/points'], g[n + '/picks'], int(g[n + '/m'])) for n in names]
 
 
