@@ -462,8 +462,17 @@ def parse_args(argv=None):
     ap.add_argument('--same-batch', action='store_true',
                     help='feed the SAME resident batch every step (rounds 1-3; scripts/timing.py:27-34 does that too) instead '
                          'of a resident ring of distinct batches: the batches of a grouped launch then alias in memory')
-    ap.add_argument('--pose-budget', type=float, default=40.0,
+    ap.add_argument('--pose-budget', type=float, default=20.0,
                     help='seconds of CPU oracle time for the pose check of the last two launch groups (outside the timed region)')
+    ap.add_argument('--pose-pairs', type=int, default=0,
+                    help='stop the pose check after this many pairs even if not every batch of the last two groups was covered '
+                         '(0: every batch gets at least one pair; the secondary passes use a few pairs each)')
+    ap.add_argument('--no-cpu-leg', action='store_true',
+                    help='pose check against the oracle, but no cpu_baseline timing (the secondary passes)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='the plain `bench.py [--gpus 1 --steps K --warmup W]` run prints the headline line only, without the '
+                         '`secondary` block (steady state, --strict, ring scans, c4, c5, single-pair latency measured by '
+                         'further child processes after the headline window)')
     ap.add_argument('--cpu-stub', action='store_true',
                     help='no GPU: gloo process group and a stand-in compute function (tests of the multi-rank plumbing)')
     ap.add_argument('--gather-every', type=int, default=None,
@@ -573,17 +582,23 @@ def pose_deltas(y, x, cfg, sd, pairs_cfg: int, sequence: bool, rows=None):
     return deltas
 
 
-def pose_check(recent, cfg, sd, pairs_cfg: int, sequence: bool, budget_s: float):
+def pose_check(recent, cfg, sd, pairs_cfg: int, sequence: bool, budget_s: float, max_pairs: int = 0):
     """Pose check over the steps in `recent` = [(batch, outputs)] (the last two launch groups): every pair while the CPU
-    budget lasts, dealt so that every batch is covered before any batch gets a second pair. Returns (deltas, pairs
-    available, batches covered)."""
+    budget lasts, dealt so that every batch is covered before any batch gets a second pair (`max_pairs` > 0: at most
+    that many pairs, taken from batches spread evenly over `recent`). Returns (deltas, pairs available, batches covered)."""
     total = sum(y.shape[0] for _, y in recent)
     if sequence or len(recent) == 1:
-        d = pose_deltas(recent[-1][1], recent[-1][0], cfg, sd, pairs_cfg, sequence)
+        rows = None if not max_pairs or sequence else list(range(min(max_pairs, recent[-1][1].shape[0])))
+        d = pose_deltas(recent[-1][1], recent[-1][0], cfg, sd, pairs_cfg, sequence, rows=rows)
         return d, total, 1
+    if max_pairs and max_pairs < len(recent):
+        keep = sorted({int(round(i * (len(recent) - 1) / max(1, max_pairs - 1))) for i in range(max_pairs)})
+        recent = [recent[i] for i in keep]
     deltas, covered, t0 = [], set(), time.perf_counter()
     for row in range(pairs_cfg):
         for i, (xb, yb) in enumerate(recent):
+            if max_pairs and len(deltas) >= max_pairs:
+                return deltas, total, len(covered)
             if time.perf_counter() - t0 > budget_s and len(covered) == len(recent):
                 return deltas, total, len(covered)
             deltas += pose_deltas(yb, xb, cfg, sd, pairs_cfg, False, rows=[row])
@@ -703,7 +718,8 @@ def run(args):
         }
         if not args.no_cpu_baseline:
             result['pose_delta_vs_oracle'] = pose_deltas(y.view(1, -1), x, cfg, sd, 1, False)[0]
-            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points)
+            if not args.no_cpu_leg:
+                result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points)
         print(json.dumps(result), flush=True)
         return
 
@@ -1086,20 +1102,112 @@ def run(args):
             result['traffic_source'] = traffic_src
         if kernels is not None:
             result['kernels_us'] = {k: round(v['avg_us'], 1) for k, v in sorted(kernels.items())}
-        if world == 1 and not args.no_cpu_baseline:
-            # pose check of the last two launch groups of the timed loop against the oracle (outside the timed region):
-            # every batch of them, as many pairs per batch as the CPU budget allows
-            deltas, available, covered = pose_check(recent_kept or [(x, y)], cfg, sd, pairs_cfg, args.sequence, args.pose_budget)
+        if not args.no_cpu_baseline:
+            # pose check of the last two launch groups of the timed loop against the oracle (outside the timed region), on
+            # rank 0 at every world size (the metric's second half): every batch of them, as many pairs per batch as the
+            # CPU budget allows. With an all-gather the outputs were written in place into its send buffer, which holds
+            # the steps of the LAST gather only: older steps are not checked there.
+            if gather is not None:
+                recent_kept = recent_kept[-min(len(recent_kept), gather.every):]
+            deltas, available, covered = pose_check(recent_kept or [(x, y)], cfg, sd, pairs_cfg, args.sequence, args.pose_budget,
+                                                    max_pairs=args.pose_pairs)
             result['pose_delta_vs_oracle'] = float(np.mean(deltas))
             result['pose_delta_max'] = float(np.max(deltas))
             result['pose_delta_pairs'] = len(deltas)
-            result['pose_delta_of'] = {'pairs_in_the_last_two_groups': available, 'batches_covered': covered,
-                                       'batches': len(recent_kept) or 1}
-            result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points, pairs_cfg=pairs_cfg)
+            result['pose_delta_of'] = {'pairs_in_the_checked_groups': available, 'batches_covered': covered,
+                                       'batches': len(recent_kept) or 1, 'rank': 0}
+            if world == 1 and not args.no_cpu_leg:
+                result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points, budget_s=8.0, pairs_cfg=pairs_cfg)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+
+# ----------------------------------------------------------------------------------------------------------
+# secondary passes: `python bench.py [--gpus 1 --steps K --warmup W]` = headline window first, then the figures
+# DESIGN.md quotes beside it, each measured by a further child process and attached as `secondary`
+# ----------------------------------------------------------------------------------------------------------
+# name -> extra arguments of the child (each child also gets --no-secondary --no-cpu-leg and a small pose check)
+SECONDARY = (
+    ('steady_200', ['--config', 'c2', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    ('strict', ['--config', 'c2', '--strict', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    ('ring', ['--config', 'c2', '--clouds', 'ring', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    ('c4', ['--config', 'c4', '--pose-pairs', '16']),
+    ('c5', ['--config', 'c5', '--pose-pairs', '4']),
+    ('latency', ['--config', 'c2', '--latency']),
+)
+SECONDARY_TIMEOUT_S = 150            # per child; a child that fails or overruns is reported as such, the headline stands
+PLAIN_FLAGS = ('--gpus', '--steps', '--warmup', '--config', '--pose-budget')
+
+
+def wants_secondary(args, argv) -> bool:
+    """The plain single-GPU c2 invocation (what the driver runs) and nothing else carries the secondary block."""
+    flags = [a for a in argv if a.startswith('--')]
+    return (args.gpus == 1 and args.config == 'c2' and not args.no_secondary and 'WORLD_SIZE' not in os.environ
+            and os.environ.get('DCLR_BENCH_CHILD') != '1' and all(f.split('=')[0] in PLAIN_FLAGS for f in flags))
+
+
+def condense(line: dict) -> dict:
+    """What a secondary pass contributes: throughput, step time, pose error, its dominant kernel's roofline fraction."""
+    roof = line.get('roofline') or {}
+    out = {'value': line.get('value'), 'unit': line.get('unit'), 'ms_per_step': line.get('ms_per_step'),
+           'steps': line.get('steps'), 'warmup': line.get('warmup'), 'mode': (line.get('config') or {}).get('mode'),
+           'workload': (line.get('config') or {}).get('workload'),
+           'pose_delta_mean': line.get('pose_delta_vs_oracle'), 'pose_delta_max': line.get('pose_delta_max', line.get('pose_delta_vs_oracle')),
+           'pose_delta_pairs': line.get('pose_delta_pairs', 1 if 'pose_delta_vs_oracle' in line else 0),
+           'dominant_kernel': roof.get('kernel'), 'frac': roof.get('frac'), 'frac_alone': roof.get('frac_alone'),
+           'avg_us': roof.get('avg_us'), 'alone_us': roof.get('alone_us')}
+    if 'latency_ms' in line:
+        out['latency_ms'] = {k: v.get('median_ms') for k, v in line['latency_ms'].items()}
+        out['kernels_us'] = line.get('kernels_us')
+    if 'latency_ms_per_batch' in line:
+        out['latency_ms_per_batch_median'] = line['latency_ms_per_batch'].get('median')
+    if line.get('roofline_sampler'):
+        rs = line['roofline_sampler']
+        out['sampler'] = {'kernel': rs.get('kernel'), 'avg_us': rs.get('avg_us'), 'alone_us': rs.get('alone_us'),
+                          'samples_per_round': rs.get('samples_per_round')}
+    return out
+
+
+def child_line(argv, timeout_s, run=subprocess.run):
+    """One child `bench.py argv` (it initialises the GPU; this process never does). Returns (json line | None, error | None)."""
+    env = dict(os.environ, DCLR_BENCH_CHILD='1')
+    t0 = time.time()
+    try:
+        res = run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True,
+                  timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return None, 'timed out after {} s'.format(timeout_s)
+    lines = [l for l in (res.stdout or '').splitlines() if l.lstrip().startswith('{')]
+    if res.returncode != 0 or not lines:
+        return None, 'exit code {} after {:.0f} s, json line seen: {}'.format(res.returncode, time.time() - t0, bool(lines))
+    try:
+        return json.loads(lines[-1]), None
+    except ValueError as exc:
+        return None, 'unparsable line: {}'.format(exc)
+
+
+def run_with_secondary(argv, run=subprocess.run, plan=SECONDARY, out=sys.stdout) -> int:
+    """Headline first (the unchanged window, a child of its own on the idle chip), then the secondary passes one after
+    another; ONE JSON line = the headline's with `secondary` attached. Any secondary failure is recorded in its slot."""
+    head, err = child_line(list(argv) + ['--no-secondary'], 900, run)
+    if head is None:
+        sys.stderr.write('bench.py: headline run failed: {}\n'.format(err))
+        return 1
+    t0 = time.time()
+    secondary = {}
+    for name, extra in plan:
+        line, err = child_line(['--gpus', '1', '--no-secondary', '--no-cpu-leg'] + list(extra), SECONDARY_TIMEOUT_S, run)
+        secondary[name] = {'error': err, 'args': ' '.join(extra)} if line is None else dict(condense(line), args=' '.join(extra))
+    secondary['note'] = ('each entry: a separate process after the headline window, same kernels and inputs policy (resident ring '
+                         'of distinct batches), untimed for `value`; pose deltas against the CPU oracle on a few pairs each; '
+                         '{:.0f} s for all of them'.format(time.time() - t0))
+    head['secondary'] = secondary
+    out.write(json.dumps(head) + '\n')
+    out.flush()
+    return 0
 
 
 def _pairs_in(name: str) -> float:
@@ -1126,6 +1234,9 @@ def main(argv=None):
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # launched as `python bench.py --gpus N`: become the launcher (no GPU call has been made in this process)
         raise SystemExit(spawn_ranks(args.gpus, argv))
+    if wants_secondary(args, argv):
+        # no GPU call has been made in this process and none will be: every measurement is a child
+        raise SystemExit(run_with_secondary(argv))
     run(args)
 
 

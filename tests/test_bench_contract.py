@@ -182,8 +182,78 @@ def test_main_becomes_the_launcher_only_without_world_size(bench, monkeypatch):
     bench.main(['--gpus', '8'])
     assert calls[-1] == ('run', 8)
     monkeypatch.delenv('WORLD_SIZE')
-    bench.main(['--gpus', '1'])
+    monkeypatch.delenv('DCLR_BENCH_CHILD', raising=False)
+    bench.main(['--gpus', '1', '--no-secondary'])
     assert calls[-1] == ('run', 1)
+    # the plain single-GPU line (the driver's command) becomes the parent of the headline and secondary children
+    monkeypatch.setattr(bench, 'run_with_secondary', lambda argv: calls.append(('secondary', list(argv))) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main(['--gpus', '1', '--steps', '20', '--warmup', '5'])
+    assert e.value.code == 0 and calls[-1] == ('secondary', ['--gpus', '1', '--steps', '20', '--warmup', '5'])
+    monkeypatch.setenv('DCLR_BENCH_CHILD', '1')            # ... whose children run the measurement themselves
+    bench.main(['--gpus', '1', '--steps', '20', '--warmup', '5'])
+    assert calls[-1] == ('run', 1)
+
+
+def test_secondary_block_is_attached_to_the_plain_single_gpu_line_only(bench, monkeypatch):
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('DCLR_BENCH_CHILD', raising=False)
+    want = lambda argv: bench.wants_secondary(bench.parse_args(argv), argv)          # noqa: E731
+    assert want([]) and want(['--gpus', '1', '--steps', '20', '--warmup', '5']) and want(['--config', 'c2'])
+    for argv in (['--strict'], ['--config', 'c4'], ['--clouds', 'ring'], ['--latency'], ['--no-secondary'], ['--h2d'],
+                 ['--no-cpu-baseline'], ['--alone-only', '3'], ['--gpus', '2'], ['--same-batch'], ['--depth', '2']):
+        assert not want(argv), argv
+    monkeypatch.setenv('WORLD_SIZE', '1')                  # python -m torch.distributed.run --nproc-per-node 1
+    assert not want([])
+
+
+def test_run_with_secondary_prints_one_line_with_every_pass_condensed(bench):
+    """The headline child runs first with the caller's own arguments; then one child per secondary pass. A pass that fails
+    fills its slot with the error; the headline line stands either way."""
+    import io
+    import types
+    seen = []
+
+    def fake_run(cmd, env=None, stdout=None, text=None, timeout=None):
+        argv = cmd[2:]
+        seen.append(argv)
+        assert env['DCLR_BENCH_CHILD'] == '1'
+        if '--strict' in argv:
+            return types.SimpleNamespace(returncode=3, stdout='')
+        if '--latency' in argv:
+            line = {'value': 1234.0, 'unit': 'scan-pairs/s', 'ms_per_step': 0.81, 'steps': 20, 'warmup': 5,
+                    'config': {'mode': 'latency', 'workload': 'one pair'}, 'pose_delta_vs_oracle': 1.5e-6,
+                    'latency_ms': {'pairwise': {'median_ms': 0.81}, 'sequential': {'median_ms': 0.79}}, 'kernels_us': {'fps': 650.0},
+                    'roofline': None}
+        else:
+            line = {'metric': 'scan-pairs/sec (2x16384 pts)', 'value': 40000.0 + len(seen), 'unit': 'scan-pairs/s', 'n_gpus': 1,
+                    'steps': 20, 'warmup': 5, 'ms_per_step': 0.2, 'config': {'mode': 'grouped', 'workload': 'w'},
+                    'pose_delta_vs_oracle': 1e-6, 'pose_delta_max': 2e-6, 'pose_delta_pairs': 4,
+                    'roofline': {'kernel': 'head_conv_fused[80x1024]', 'frac': 0.2, 'frac_alone': 0.44, 'avg_us': 1000.0, 'alone_us': 460.0},
+                    'roofline_sampler': {'kernel': 'fps_clouds[160x16384]', 'avg_us': 1400.0, 'alone_us': 700.0, 'samples_per_round': 3.1},
+                    'latency_ms_per_batch': {'median': 9.6}}
+        return types.SimpleNamespace(returncode=0, stdout='noise\n' + json.dumps(line) + '\n')
+
+    out = io.StringIO()
+    assert bench.run_with_secondary(['--gpus', '1', '--steps', '20', '--warmup', '5'], run=fake_run, out=out) == 0
+    assert seen[0] == ['--gpus', '1', '--steps', '20', '--warmup', '5', '--no-secondary']      # the headline window, unchanged, first
+    assert all('--no-secondary' in a and '--no-cpu-leg' in a for a in seen[1:]) and len(seen) == 1 + len(bench.SECONDARY)
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1
+    doc = json.loads(lines[0])
+    assert doc['value'] == 40001.0 and doc['steps'] == 20                                       # the headline's own figures
+    sec = doc['secondary']
+    assert set(sec) == {n for n, _ in bench.SECONDARY} | {'note'}
+    assert {'steady_200', 'strict', 'ring', 'c4', 'c5'} <= set(sec)
+    assert sec['strict']['error'].startswith('exit code 3') and '--strict' in sec['strict']['args']
+    for name in ('steady_200', 'ring', 'c4', 'c5'):
+        e = sec[name]
+        assert e['value'] > 40000 and e['ms_per_step'] == 0.2 and e['pose_delta_max'] == 2e-6 and e['pose_delta_pairs'] == 4
+        assert e['dominant_kernel'] == 'head_conv_fused[80x1024]' and e['frac'] == 0.2 and e['frac_alone'] == 0.44
+        assert e['sampler']['alone_us'] == 700.0 and e['latency_ms_per_batch_median'] == 9.6
+    assert sec['latency']['latency_ms'] == {'pairwise': 0.81, 'sequential': 0.79} and sec['latency']['pose_delta_max'] == 1.5e-6
+    # a failing headline is a failing run
+    assert bench.run_with_secondary([], run=lambda *a, **k: types.SimpleNamespace(returncode=1, stdout=''), out=io.StringIO()) == 1
 
 
 def test_output_gather_bookkeeping_world_size_2(bench, tmp_path):
@@ -254,6 +324,12 @@ def test_pose_check_covers_every_batch_before_any_batch_gets_a_second_pair(bench
     calls.clear()
     deltas, _, covered = bench.pose_check(recent, None, None, 8, False, budget_s=1e9)           # ample budget: every pair
     assert len(deltas) == 40 and covered == 5 and calls[5] == (0, (1,))
+    calls.clear()
+    deltas, _, covered = bench.pose_check(recent, None, None, 8, False, budget_s=1e9, max_pairs=3)   # the secondary passes' cap
+    assert len(deltas) == 3 and [c[0] for c in calls] == [0, 2, 4]                               # spread over the window
+    calls.clear()
+    deltas, _, _ = bench.pose_check(recent, None, None, 8, False, budget_s=1e9, max_pairs=7)
+    assert len(deltas) == 7 and calls[5] == (0, (1,))
 
 
 def test_cpu_baseline_reports_batch_one_and_the_configurations_batch(bench):
