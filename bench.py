@@ -962,6 +962,8 @@ def run(args):
         print('host trace (us after t0, per step): ' + ' '.join('%.0f' % (1e6 * v) for v in host_trace) +
               ' | closing fence returned at %.0f' % (1e6 * elapsed), file=sys.stderr)
     ops.TIMER = None
+    if not stub:
+        model.check_range()                      # the split-f16 kernels' sticky flag: a clamped activation = wrong poses = no line
     recent_kept = list(recent)                   # the last two launch groups of the TIMED loop (pose check below)
     alone, fps_rounds, latency = None, None, None
     if rank == 0 and not stub and world == 1:

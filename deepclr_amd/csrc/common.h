@@ -17,6 +17,20 @@ static inline int dclr_launch_status() {
     return e == hipSuccess ? DCLR_OK : -(1000 + (int)e);
 }
 
+// ---- library-internal forms of two level-2 entry points (not exported): the split-f16 kernels with the word that
+// receives 1 when an activation left the f16 range (overflow, NULL = not reported), and -- flow embedding -- a buffer of
+// zero_count floats the kernel clears on its way (the head's column maxima: saves the fill launch between the two).
+#define DCLR_INTERNAL __attribute__((visibility("hidden")))
+DCLR_INTERNAL int dclr_x_head_conv_fused_f16(int m, int n_layers, int k_in, const int *k_host, const int *n_host,
+                                             const void *const *w_packed_host, const float *const *bias_host,
+                                             const float *x, int ldx, float *colmax, int rows_per_group,
+                                             uint32_t *overflow, dclr_stream_t stream);
+DCLR_INTERNAL int dclr_x_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, const float *f_rows,
+                                                  const int32_t *knn_idx, const float *pt, const float *ps,
+                                                  const float *w1a, const float *b1, const void *w2p, const float *b2,
+                                                  const void *w3p, const float *b3, float *e_rows, float *zero,
+                                                  long long zero_count, uint32_t *overflow, dclr_stream_t stream);
+
 // ---- frozen distance recipe (include/deepclr_amd.h): (dx*dx + dy*dy) + dz*dz, no contraction.
 // The whole library is built with -ffp-contract=off; MLP code asks for FMA explicitly (fmaf).
 __device__ __forceinline__ float dclr_sqdist(float ax, float ay, float az, float bx, float by, float bz) {

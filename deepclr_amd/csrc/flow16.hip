@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                                                      const float *__restrict__ w1a, const float *__restrict__ b1,
                                                      const float4 *__restrict__ w2p, const float *__restrict__ b2,
                                                      const float4 *__restrict__ w3p, const float *__restrict__ b3,
-                                                     float *__restrict__ e_rows) {
+                                                     float *__restrict__ e_rows, float *__restrict__ zero,
+                                                     long long zero_count, uint32_t *overflow) {
     __shared__ __attribute__((aligned(16))) char tile[T * 16 * F16_STRIDE];
     __shared__ uint32_t vbits[F16_G];
 
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
         blk = (size_t)((i / per_pair) * 8u + xcd) * per_pair + i % per_pair;
     }
     const size_t g0 = blk * F16_G;
+    // the buffer the NEXT launch on this stream accumulates into with atomic maxima (the head's column maxima)
+    if (zero != nullptr)
+        for (long long i = (long long)blockIdx.x * 256 + tid; i < zero_count; i += (long long)gridDim.x * 256) zero[i] = 0.f;
 
     // ---- phase A: wave w builds the layer-1 rows of template point g0 + w (lane = channels 2l, 2l+1) ----
     {
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
         const bool live = gp < total && !(ABL & 4);                     // wave-uniform
         uint32_t bits = 0;
         int s_done = 0;
+        float peak = 0.f;
         // channels 2 lane, 2 lane + 1 sit in octet lane / 4 at half positions 2 (lane % 4), + 1
         char *const slot = tile + f16_octet_offset(lane >> 2) + 4 * (lane & 3);
         if (live) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                     v0 = fmaf(wa0, dx, v0); v0 = fmaf(wa1, dy, v0); v0 = fmaf(wa2, dz, v0);
                     v1 = fmaf(wb0, dx, v1); v1 = fmaf(wb1, dy, v1); v1 = fmaf(wb2, dz, v1);
                     dclr_h2 hi, lo;
-                    dclr_split2_relu(v0, v1, hi, lo);
+                    dclr_split2_relu(v0, v1, hi, lo, peak);
                     const int row = (s >> 2) * 16 + 4 * p + (s & 3);
                     *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE) = hi;
                     *reinterpret_cast<dclr_h2 *>(slot + row * F16_STRIDE + 16) = lo;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
             *reinterpret_cast<uint32_t *>(slot + row * F16_STRIDE + 16) = 0u;
         }
         if (lane == 0) vbits[p] = bits;
+        dclr_report_overflow(overflow, peak);
     }
     __syncthreads();
 
@@ -205,6 +211,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
         const float4 *wh = w2p + (size_t)(2 * wave) * F16_KG * 64 + lane;
         flow16_panel<T, true, ABL>(acc, acc2, a_lane, wh, wh + (size_t)(F16_C / 16) * F16_KG * 64, F16_KG * 64);
         __syncthreads();                                   // every wave has consumed the layer-1 rows
+        float peak = 0.f;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int ch = (2 * wave + u) * 16 + 4 * kq;   // registers i = channels ch + i of neighbour row c16
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                 for (int i = 0; i < 4; i += 2) {
                     dclr_h2 a, b;
                     dclr_split2_relu(fmaf(acc2[t][u][i], DCLR_SPLIT_INV, acc[t][u][i]),
-                                     fmaf(acc2[t][u][i + 1], DCLR_SPLIT_INV, acc[t][u][i + 1]), a, b);
+                                     fmaf(acc2[t][u][i + 1], DCLR_SPLIT_INV, acc[t][u][i + 1]), a, b, peak);
                     hi[i] = a[0]; hi[i + 1] = a[1]; lo[i] = b[0]; lo[i + 1] = b[1];
                 }
                 char *dst = tile + (t * 16 + c16) * F16_STRIDE + f16_octet_offset(ch >> 3) + 2 * (ch & 7);
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
                 *reinterpret_cast<dclr_h4 *>(dst + 16) = lo;
             }
         }
+        dclr_report_overflow(overflow, peak);
     }
     __syncthreads();
 
@@ -277,11 +285,12 @@ __global__ __launch_bounds__(256, T <= 5 ? 3 : 2) void flow16_kernel(int pairs, 
 template <int T, int ABL = 0>
 void flow16_launch(int pairs, int npoint, int k, float radius, const float *f_rows, const int32_t *knn_idx,
                    const float *pt, const float *ps, const float *w1a, const float *b1, const void *w2p,
-                   const float *b2, const void *w3p, const float *b3, float *e_rows, hipStream_t stream) {
+                   const float *b2, const void *w3p, const float *b3, float *e_rows, hipStream_t stream,
+                   float *zero = nullptr, long long zero_count = 0, uint32_t *overflow = nullptr) {
     const size_t total = (size_t)pairs * npoint;
     hipLaunchKernelGGL((flow16_kernel<T, ABL>), dim3((unsigned)((total + F16_G - 1) / F16_G)), dim3(256), 0, stream, pairs,
                        npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, reinterpret_cast<const float4 *>(w2p), b2,
-                       reinterpret_cast<const float4 *>(w3p), b3, e_rows);
+                       reinterpret_cast<const float4 *>(w3p), b3, e_rows, zero, zero_count, overflow);
 }
 
 }  // namespace
@@ -290,6 +299,15 @@ extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float
                                              const int32_t *knn_idx, const float *pt, const float *ps,
                                              const float *w1a, const float *b1, const void *w2p, const float *b2,
                                              const void *w3p, const float *b3, float *e_rows, dclr_stream_t stream) {
+    return dclr_x_flow_embedding_fused_f16(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows,
+                                           nullptr, 0, nullptr, stream);
+}
+
+int dclr_x_flow_embedding_fused_f16(int pairs, int npoint, int k, float radius, const float *f_rows, const int32_t *knn_idx,
+                                    const float *pt, const float *ps, const float *w1a, const float *b1, const void *w2p,
+                                    const float *b2, const void *w3p, const float *b3, float *e_rows, float *zero,
+                                    long long zero_count, uint32_t *overflow, dclr_stream_t stream) {
+    DCLR_REQUIRE(zero == nullptr || zero_count > 0);
     DCLR_REQUIRE(pairs > 0 && npoint > 0 && f_rows && knn_idx && pt && ps && w1a && b1 && w2p && b2 && w3p &&
                  b3 && e_rows);
     if (k < 1 || k > 32) return DCLR_E_UNSUPPORTED;
@@ -307,7 +325,7 @@ extern "C" int dclr_flow_embedding_fused_f16(int pairs, int npoint, int k, float
         return dclr_launch_status();
     }
 #endif
-#define DCLR_FLOW16_CASE(T) case T: flow16_launch<T>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st); break
+#define DCLR_FLOW16_CASE(T) case T: flow16_launch<T>(pairs, npoint, k, radius, f_rows, knn_idx, pt, ps, w1a, b1, w2p, b2, w3p, b3, e_rows, st, zero, zero_count, overflow); break
     switch ((k + 3) / 4) {
         DCLR_FLOW16_CASE(1); DCLR_FLOW16_CASE(2); DCLR_FLOW16_CASE(3); DCLR_FLOW16_CASE(4);
         DCLR_FLOW16_CASE(5); DCLR_FLOW16_CASE(6); DCLR_FLOW16_CASE(7); DCLR_FLOW16_CASE(8);

@@ -35,23 +35,27 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
         mark();                             // slot 3 doubles as the start of the flow-embedding span
     }
     if (!(a->stages & 2)) return DCLR_OK;
-    if (a->precision == 1)
-        rc = dclr_flow_embedding_fused_f16(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps,
-                                           a->w1a, a->b1, a->w2, a->b2, a->w3, a->b3, a->e_rows, stream);
+    const int n_last = a->head_n[a->n_head_layers - 1];
+    const long long n_colmax = (long long)a->pairs * n_last;
+    if (a->precision == 1)          // the split-f16 flow kernel also clears the head's column maxima (no fill launch)
+        rc = dclr_x_flow_embedding_fused_f16(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps,
+                                             a->w1a, a->b1, a->w2, a->b2, a->w3, a->b3, a->e_rows, a->colmax, n_colmax,
+                                             a->overflow, stream);
     else
         rc = dclr_flow_embedding_fused(a->pairs, a->npoint, a->k, a->radius, a->f_rows, a->knn_idx, a->pt, a->ps, a->w1a,
                                        a->b1, (const float *)a->w2, a->b2, (const float *)a->w3, a->b3, a->e_rows, stream);
     if (rc != DCLR_OK) return rc;
     mark();
-    const int n_last = a->head_n[a->n_head_layers - 1];
-    const hipError_t ms = hipMemsetAsync(a->colmax, 0, (size_t)a->pairs * n_last * sizeof(float), st);
-    if (ms != hipSuccess) {
-        (void)hipGetLastError();                            // consume the sticky copy; the code below carries the error
-        return -(1000 + (int)ms);
+    if (a->precision != 1) {
+        const hipError_t ms = hipMemsetAsync(a->colmax, 0, (size_t)n_colmax * sizeof(float), st);
+        if (ms != hipSuccess) {
+            (void)hipGetLastError();                        // consume the sticky copy; the code below carries the error
+            return -(1000 + (int)ms);
+        }
     }
     if (a->precision == 1)
-        rc = dclr_head_conv_fused_f16(rows, a->n_head_layers, a->head_k_in, a->head_k, a->head_n, a->head_w, a->head_b,
-                                      a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);
+        rc = dclr_x_head_conv_fused_f16(rows, a->n_head_layers, a->head_k_in, a->head_k, a->head_n, a->head_w, a->head_b,
+                                        a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, a->overflow, stream);
     else
         rc = dclr_head_conv_fused(rows, a->n_head_layers, a->head_k, a->head_n, (const float *const *)a->head_w, a->head_b,
                                   a->e_rows, DCLR_E_STRIDE, a->colmax, a->npoint, stream);

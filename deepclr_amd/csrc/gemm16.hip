@@ -63,6 +63,7 @@ struct Head16Params {
     int n[H16_MAX_LAYERS];                  // output width (multiple of 32)
     const float4 *w[H16_MAX_LAYERS];        // packed hi plane; lo plane follows at n * k / 8 fragments
     const float *b[H16_MAX_LAYERS];
+    uint32_t *overflow;                     // NULL, or the word that receives 1 when an activation left the f16 range
 };
 
 // K loop for NT weight tiles x MT point tiles. LAST: activations are the A operand (X * W^T).
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
     {
         const int stride = dclr_split_stride(prm.k[0]);
         const int octets = prm.k[0] / 8, valid = prm.k_in / 8;
+        float peak = 0.f;
         for (int e = tid; e < ROWS * octets; e += H16_WAVES * 64) {
             const int r = e / octets, o = e - r * octets;
             dclr_h8 hi, lo;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
                     dclr_h2 a, b;
-                    dclr_split2(v[q], v[q + 1], a, b);
+                    dclr_split2(v[q], v[q + 1], a, b, peak);
                     hi[q] = a[0]; hi[q + 1] = a[1]; lo[q] = b[0]; lo[q + 1] = b[1];
                 }
             } else {
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
             *reinterpret_cast<dclr_h8 *>(dst) = hi;
             *reinterpret_cast<dclr_h8 *>(dst + 16) = lo;
         }
+        dclr_report_overflow(prm.overflow, peak);
     }
     __syncthreads();
 
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
             }
             __syncthreads();                                   // layer input fully consumed: overwrite in place
             if (any) {
+                float peak = 0.f;                              // lives through this epilogue only (the K loop sits at 249 registers)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u == 1 && !two) break;
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
                                 dclr_h2 a, b;
                                 dclr_split2_relu(fmaf(acc2[u][t][4 * g4 + i], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i]),
                                                  fmaf(acc2[u][t][4 * g4 + i + 1], DCLR_SPLIT_INV, acc[u][t][4 * g4 + i + 1]),
-                                                 a, b);
+                                                 a, b, peak);
                                 hi[i] = a[0]; hi[i + 1] = a[1]; lo[i] = b[0]; lo[i + 1] = b[1];
                             }
                             char *dst = act + (32 * t + j) * out_stride + 32 * (4 * tt + g4) + 8 * h;
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(H16_WAVES * 64) void head16_kernel(Head16Params prm
                         }
                     }
                 }
+                dclr_report_overflow(prm.overflow, peak);
             }
             __syncthreads();
         } else {
@@ -343,6 +348,13 @@ extern "C" int dclr_head_conv_fused_f16(int m, int n_layers, int k_in, const int
                                         const void *const *w_packed_host, const float *const *bias_host,
                                         const float *x, int ldx, float *colmax, int rows_per_group,
                                         dclr_stream_t stream) {
+    return dclr_x_head_conv_fused_f16(m, n_layers, k_in, k_host, n_host, w_packed_host, bias_host, x, ldx, colmax,
+                                      rows_per_group, nullptr, stream);
+}
+
+int dclr_x_head_conv_fused_f16(int m, int n_layers, int k_in, const int *k_host, const int *n_host,
+                               const void *const *w_packed_host, const float *const *bias_host, const float *x, int ldx,
+                               float *colmax, int rows_per_group, uint32_t *overflow, dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n_layers >= 1 && k_host && n_host && w_packed_host && bias_host && x && colmax);
     DCLR_REQUIRE(m % 32 == 0 && rows_per_group > 0 && rows_per_group % 32 == 0 && m % rows_per_group == 0);
     DCLR_REQUIRE(k_in > 0 && k_in % 8 == 0 && ldx % 4 == 0 && ldx >= k_in && k_in <= k_host[0] && ((uintptr_t)x & 15) == 0);
@@ -350,6 +362,7 @@ extern "C" int dclr_head_conv_fused_f16(int m, int n_layers, int k_in, const int
     Head16Params prm{};
     prm.n_layers = n_layers;
     prm.k_in = k_in;
+    prm.overflow = overflow;
     for (int l = 0; l < n_layers; ++l) {
         DCLR_REQUIRE(w_packed_host[l] && bias_host[l] && k_host[l] > 0 && n_host[l] > 0);
         DCLR_REQUIRE(k_host[l] % 16 == 0 && n_host[l] % 32 == 0 && ((uintptr_t)w_packed_host[l] & 15) == 0 &&

@@ -59,6 +59,23 @@ __device__ __forceinline__ void dclr_split2(float v0, float v1, dclr_h2 &hi, dcl
     dclr_split2_clamped(c, hi, lo);
 }
 
+// The same two, remembering in `peak` the largest value (magnitude) that entered the clamp: one v_max3_f32 per two values.
+// A kernel compares `peak` with DCLR_F16_MAX once per phase and reports through dclr_report_overflow -- the clamp is silent
+// otherwise, and activations beyond 65504 would turn into wrong poses without a message.
+__device__ __forceinline__ void dclr_split2_relu(float v0, float v1, dclr_h2 &hi, dclr_h2 &lo, float &peak) {
+    peak = fmaxf(fmaxf(v0, v1), peak);
+    dclr_split2_relu(v0, v1, hi, lo);
+}
+__device__ __forceinline__ void dclr_split2(float v0, float v1, dclr_h2 &hi, dclr_h2 &lo, float &peak) {
+    peak = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), peak);
+    dclr_split2(v0, v1, hi, lo);
+}
+// flag: NULL, or one word any later reader polls (device memory, or host memory mapped into the device's address space:
+// a plain system-scope store of the constant 1, so it needs no atomic the link may lack). Sticky: never cleared here.
+__device__ __forceinline__ void dclr_report_overflow(uint32_t *flag, float peak) {
+    if (flag != nullptr && peak > DCLR_F16_MAX) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // LDS row stride in BYTES for kp values per row (kp % 16 == 0): 4 kp + 16, i.e. (stride / 16) odd, so the
 // 16 or 32 rows addressed by one ds_read_b128 fall into distinct 16-byte bank groups.
 __host__ __device__ constexpr int dclr_split_stride(int kp) { return 4 * kp + 16; }

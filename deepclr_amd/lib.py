@@ -70,6 +70,7 @@ class MergeArgs(ctypes.Structure):
         ('head_w', _p * MERGE_MAX_LAYERS), ('head_b', _p * MERGE_MAX_LAYERS),
         ('fc_w', _p * MERGE_MAX_FC), ('fc_b', _p * MERGE_MAX_FC),
         ('pt', _p), ('ps', _p), ('knn_idx', _p), ('e_rows', _p), ('colmax', _p), ('fc_tmp', _p * 2), ('y', _p),
+        ('overflow', _p),
     ]
 
 
@@ -140,6 +141,28 @@ def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_contiguous():
         raise RuntimeError("{} must be contiguous".format(name))
     return t
+
+
+class MappedFlag:
+    """One int32 of pinned host memory that kernels can write through `dev_ptr` (the host allocation mapped into the
+    device's address space) and the host can read at any time without a device synchronisation -- the sticky
+    activation-range flag of the split-f16 kernels (DclrMergeArgs.overflow, include/deepclr_amd.h)."""
+
+    def __init__(self):
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.view = self.host.numpy()
+        hip = ctypes.CDLL('libamdhip64.so')
+        dev = ctypes.c_void_p()
+        rc = hip.hipHostGetDevicePointer(ctypes.byref(dev), ctypes.c_void_p(self.host.data_ptr()), 0)
+        if rc != 0 or not dev.value:
+            raise RuntimeError("hipHostGetDevicePointer failed for the range flag (code {})".format(rc))
+        self.dev_ptr = dev.value
+
+    def is_set(self) -> bool:
+        return bool(self.view[0])
+
+    def clear(self) -> None:
+        self.view[0] = 0
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -606,7 +606,7 @@ class _MergePlan:
         return self._versions == self._version_key(self._keep['mods'])
 
     @classmethod
-    def build(cls, flow, head, device, pairs: int, npoint: int):
+    def build(cls, flow, head, device, pairs: int, npoint: int, overflow_ptr: Optional[int] = None):
         rows = pairs * npoint
         f16 = ops.PRECISION == 'f16x2'
         layers = head._packed_f16() if f16 else head._packed()
@@ -620,6 +620,7 @@ class _MergePlan:
         a = lib.MergeArgs()
         a.pairs, a.npoint, a.k, a.precision, a.radius = pairs, npoint, flow._k, int(f16), flow._radius
         a.n_head_layers, a.head_k_in, a.n_fc = len(layers), ops.E_STRIDE, len(fcs)
+        a.overflow = overflow_ptr                   # the split-f16 kernels report a clamped activation there
         keep = {'mods': [flow, head], 'tensors': [p, layers]}
 
         def dev(t):
@@ -811,6 +812,7 @@ class DeepCLR(BaseModel):
         self._rows_path = all(getattr(mod, 'rows_path', False) for mod in (cloud, merge_layer, head))
         self._plans: Dict[Any, Any] = {}
         self._range_ok = None                       # weights key of the last checked forward that passed (ops.CHECK_RANGE)
+        self._range_flag = None                     # lib.MappedFlag: set by the split-f16 kernels when a clamp engages
         if loss is None:
             self._loss_layer = None
         elif isinstance(loss, list):
@@ -878,6 +880,7 @@ class DeepCLR(BaseModel):
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and (
                 ops.CHECK_RANGE == 'always' or self._range_unchecked() or sa0.range_unchecked()):
             return None
+        self.check_range()
         per, nb, stride = view if view is not None else (x.shape[0] // 2, 1, 0)
         plan = self._cloud_plan(sa0, x, per, nb)
         if plan is None:
@@ -924,7 +927,8 @@ class DeepCLR(BaseModel):
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
-        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' and not self.training \
+        self.check_range()
+        if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' \
                 and (ops.CHECK_RANGE == 'always' or self._range_unchecked()):
             return self._merge_rows_checked(f_rows, pairs, out)
         plan = self._merge_plan(f_rows, pairs)
@@ -936,6 +940,34 @@ class DeepCLR(BaseModel):
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         y = self._merge_layers[1].forward_rows(e_rows, pairs)
         return y if out is None else out.copy_(y)
+
+    def _range_flag_ptr(self) -> Optional[int]:
+        if ops.PRECISION != 'f16x2':
+            return None
+        if self._range_flag is None:
+            self._range_flag = lib.MappedFlag()
+        return self._range_flag.dev_ptr
+
+    def check_range(self, synchronize: bool = False) -> None:
+        """Raise if a split-f16 forward that has COMPLETED since the last check clamped an activation at 65504 (its poses
+        are wrong). The fused kernels set one word of mapped host memory when a clamp engages (csrc/mma16f.h
+        dclr_report_overflow); reading it costs no device synchronisation, so every entry into the model looks at it --
+        forward(), merge_rows(), the pipelined runner's steps -- and a caller that wants the verdict for work still in
+        flight passes synchronize=True. CHECK_RANGE='first' covers the first forward of a checkpoint (f32 re-run with
+        a message that names the peak); this flag covers every later input."""
+        flag = self._range_flag
+        if flag is None:
+            return
+        if ops.CHECK_RANGE == 'never':              # the caller opted out of range checks: nothing is reported, nothing kept
+            flag.clear()
+            return
+        if synchronize:
+            torch.cuda.synchronize()
+        if flag.is_set():
+            flag.clear()
+            raise RuntimeError("split-f16 matrix path out of range: an activation exceeded 65504 and was clamped in a forward "
+                               "pass completed since the last check -- the poses of that pass are wrong. Run this "
+                               "checkpoint with DCLR_PRECISION=f32.")
 
     def _range_key(self):
         return tuple((p.data_ptr(), p._version) for m in self._merge_layers for p in flat_parameters(m))
@@ -979,7 +1011,7 @@ class DeepCLR(BaseModel):
         key = (f_rows.device, pairs, self.npoint, ops.PRECISION, lib.stream_ptr())
         plan = self._plans.get(key)
         if plan is None or not plan.current():
-            plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint)
+            plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint, self._range_flag_ptr())
             if plan is None:
                 return None
             if len(self._plans) > 16:

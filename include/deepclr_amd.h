@@ -280,7 +280,9 @@ int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const fl
  * host, not the GPU, bounds the step once these take ~0.25 ms: one foreign call and no allocation per batch.
  * All buffers are the caller's; the workspace may be reused by the next call on the same stream.
  * events: NULL, or DCLR_MERGE_EVENTS hipEvent_t handles recorded on `stream` before the first launch and after
- * each stage (slot order: start, pt, ps, knn, flow, head, then one per fully connected layer). */
+ * each stage (slot order: start, pt, ps, knn, flow, head, then one per fully connected layer).
+ * Range of the split-fp16 path (precision == 1): operands beyond +-65504 are clamped; the kernels report it through
+ * `overflow` (below) instead of returning wrong poses silently. */
 #define DCLR_MERGE_MAX_LAYERS 8
 #define DCLR_MERGE_MAX_FC 4
 #define DCLR_MERGE_EVENTS (6 + DCLR_MERGE_MAX_FC)
@@ -306,6 +308,9 @@ typedef struct DclrMergeArgs {
     float *colmax;                          /* workspace (pairs, head_n[last]) */
     float *fc_tmp[2];                       /* workspace (pairs, max fc width) each */
     float *y;                               /* out (pairs, fc_n[last]) */
+    uint32_t *overflow;                     /* NULL, or one word (device memory, or host memory mapped into the device's
+                                             * address space) that the split-fp16 kernels set to 1 when an activation
+                                             * exceeds 65504 and is clamped (precision == 1); sticky: the caller clears it */
 } DclrMergeArgs;
 int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
 

@@ -385,3 +385,21 @@ def test_flat_parameters_follows_late_registrations_and_replicas():
     shared = torch.nn.Linear(2, 2)
     tied = torch.nn.Sequential(shared, shared)                             # the same parameters twice: listed once, as parameters() does
     assert len(flat_parameters(tied)) == 2
+
+
+def test_argument_structs_match_the_header_byte_for_byte(tmp_path):
+    """lib.MergeArgs / lib.CloudArgs are ctypes mirrors of DclrMergeArgs / DclrCloudArgs (include/deepclr_amd.h): compile
+    the header with gcc and compare sizes and the offsets of the last members (a field added on one side only would shift
+    every pointer behind it)."""
+    import subprocess
+    from deepclr_amd import lib
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "deepclr_amd.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(DclrMergeArgs), offsetof(DclrMergeArgs, y), '
+                   'offsetof(DclrMergeArgs, overflow), sizeof(DclrCloudArgs), offsetof(DclrCloudArgs, f_rows), '
+                   'offsetof(DclrCloudArgs, merge)); return 0; }\n')
+    exe = tmp_path / 'sizes'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    m, c = lib.MergeArgs, lib.CloudArgs
+    assert got == [ctypes.sizeof(m), m.y.offset, m.overflow.offset, ctypes.sizeof(c), c.f_rows.offset, c.merge.offset]
