@@ -254,8 +254,9 @@ class MotionEmbeddingBase(nn.Module):
             h = torch.cat((pos_diff, feat_t.expand(-1, -1, -1, k), grouped[:, d:]), dim=1)
         else:
             h = torch.cat((pos_diff, grouped[:, d:] - feat_t), dim=1)
-        for w, bias in self._conv.affine_params():
-            h = F.relu(F.conv2d(h, w.unsqueeze(-1), bias))
+        # the reference's Conv1dMultiLayer on (groups, C, k) rows (deepclr.py:212-217): the torch modules themselves, so that
+        # batch norm (statistics over every group and neighbour, per channel) and dropout act as they do there
+        h = self._conv.forward_torch(h.reshape(b, h.shape[1], p0 * k)).reshape(b, -1, p0, k)
         if self._radius > 0.0:
             h = h.masked_fill((torch.norm(pos_diff, dim=1) >= self._radius).unsqueeze(1), 0.0)
         return torch.cat((clouds0[:, :d, :], h.max(dim=3)[0]), dim=1).contiguous()
@@ -485,14 +486,8 @@ class OutputSimple(DeepCLRModule):
     def forward_train(self, x: torch.Tensor) -> torch.Tensor:
         """forward() with a gradient (reference: deepclr.py:284-294 under autograd; the output activation is applied out of
         place, the reference's in-place writes into y give the same values)."""
-        if self.training and any(isinstance(m, nn.Dropout) for m in self.linear._sequential):
-            raise NotImplementedError("dropout_keep < 1 is outside this build (every shipped configuration has dropout: 1.0)")
-        h = x
-        for w, bias in self.conv.affine_params():
-            h = F.relu(F.conv1d(h, w, bias))
-        h = h.max(dim=2)[0]
-        for w, bias in self.linear.affine_params():
-            h = F.relu(F.linear(h, w, bias))
+        h = self.conv.forward_torch(x).max(dim=2)[0]        # the torch modules themselves: batch norm and dropout as the
+        h = self.linear.forward_torch(h)                    # reference applies them (helper.py:92-93,122-123)
         y = F.linear(h, self.output.weight, self.output.bias)
         if self._act == 2:                          # dual quaternion: sigmoid on column 0, tanh on 1..3
             y = torch.cat((torch.sigmoid(y[:, :1]), torch.tanh(y[:, 1:4]), y[:, 4:]), dim=1)
@@ -612,7 +607,7 @@ class _MergePlan:
         layers = head._packed_f16() if f16 else head._packed()
         if not head._fusable(head._packed(), rows, pairs) or (not f16 and rows < 4096) or flow._k == 0:
             return None                             # (GlobalGrouping runs slice by slice through forward_rows)
-        fcs = [(m.affine.weight, m.affine.bias, 1) for m in head.linear.layers()]
+        fcs = [(*m.folded(), 1) for m in head.linear.layers()]         # eval-mode batch norm folded in; dropout = identity
         fcs.append((head.output.weight, head.output.bias, head._act))
         if len(layers) > lib.MERGE_MAX_LAYERS or len(fcs) > lib.MERGE_MAX_FC or any(b is None for _, b, _ in fcs):
             return None
@@ -810,6 +805,9 @@ class DeepCLR(BaseModel):
         # layer widths / k / feature counts runs module by module in the reference's channel layout, every module composed
         # from the level-1 HIP operators where its own shape is not the fused one.
         self._rows_path = all(getattr(mod, 'rows_path', False) for mod in (cloud, merge_layer, head))
+        # batch norm / dropout (`batch_norm: true`, `dropout` < 1): identity-like in eval mode (folded / skipped), but in
+        # training mode they need batch statistics / random masks, which only the differentiable torch path provides
+        self._train_only = any(isinstance(m, (nn.Dropout, nn.modules.batchnorm._BatchNorm)) for m in self.modules())
         self._plans: Dict[Any, Any] = {}
         self._range_ok = None                       # weights key of the last checked forward that passed (ops.CHECK_RANGE)
         self._range_flag = None                     # lib.MappedFlag: set by the split-f16 kernels when a clamp engages
@@ -927,6 +925,7 @@ class DeepCLR(BaseModel):
         """Rows F -> pose outputs (pairs, label_dim). Shapes the one-call path covers (MotionEmbedding +
         OutputSimple, fusable head) go through dclr_merge_forward: one foreign call and one allocation per batch
         instead of ten and a dozen -- at ~0.3 ms per step the host would otherwise set the pace."""
+        self._refuse_training_modules()
         self.check_range()
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never' \
                 and (ops.CHECK_RANGE == 'always' or self._range_unchecked()):
@@ -940,6 +939,12 @@ class DeepCLR(BaseModel):
         e_rows = self._merge_layers[0].forward_rows(f_rows, pairs, self.npoint)
         y = self._merge_layers[1].forward_rows(e_rows, pairs)
         return y if out is None else out.copy_(y)
+
+    def _refuse_training_modules(self) -> None:
+        if self.training and self._train_only:
+            raise RuntimeError("this model has batch norm / dropout layers and is in training mode: the inference kernels fold "
+                               "the running statistics and skip dropout, which is what eval() means -- call model.eval() "
+                               "(ModelInferenceHelper does); a training step runs with gradients enabled")
 
     def _range_flag_ptr(self) -> Optional[int]:
         if ops.PRECISION != 'f16x2':
@@ -1057,6 +1062,8 @@ class DeepCLR(BaseModel):
             raise RuntimeError("batch must hold templates followed by the same number of sources")
         pairs = x.shape[0] // 2
         f_rows = None
+        if not torch.is_grad_enabled():
+            self._refuse_training_modules()
         if self.training and torch.is_grad_enabled():
             # Training step (reference: engine/engines.py:57-84 runs forward with m and y, then loss.backward()): module by
             # module in the reference's channel layout with a gradient -- sampling / ball query / kNN on the HIP operators

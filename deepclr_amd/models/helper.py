@@ -6,67 +6,101 @@ bias, ReLU after EVERY layer including the last, and the nesting
 ``_sequential.{i}._sequential.0.{weight,bias}`` that the shipped checkpoints use.
 Here the modules are parameter holders plus a forward that calls the MFMA GEMM
 (``dclr_linear``) or the small-row FC kernel (``dclr_fc``); they never run on CPU.
+
+``batch_norm=True`` (helper.py:27-30,57-60: a BatchNorm1d behind the affine layer, inside the same
+``_sequential``) and ``dropout_keep < 1`` (helper.py:77-85,107-113) build the same module trees as the
+reference, hence the same state_dict keys. In eval mode -- what ``ModelInferenceHelper`` sets and what
+every inference script runs -- batch norm is the affine map of its running statistics and is FOLDED into
+the layer's weight and bias before they are packed for the kernels (``folded()``); dropout is the
+identity. In training mode both need batch statistics / random masks: the differentiable training step
+runs the torch modules themselves (``forward_torch``), the fused inference kernels refuse.
 """
 from typing import List, Optional, Tuple
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
 
 
-def _no_batch_norm(batch_norm: bool) -> None:
-    if batch_norm:
-        raise NotImplementedError("batch_norm=True is outside the MI355X hot path (every shipped "
-                                  "model_config.yaml sets batch_norm: false)")
+def fold_batch_norm(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional[nn.modules.batchnorm._BatchNorm])\
+        -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(W, b) of `bn(W x + b)` in eval mode: W' = s W, b' = s (b - mean) + beta with s = gamma / sqrt(var + eps).
+    Without a norm layer the parameters themselves come back (no copy). Float64 inside: the fold is done once per
+    checkpoint and must not cost accuracy against torch's own eval-mode kernel."""
+    if bn is None:
+        return weight, bias
+    if bn.training:
+        raise RuntimeError("batch norm in training mode normalises with batch statistics: the inference kernels fold the "
+                           "RUNNING statistics into the layer (call model.eval(), as ModelInferenceHelper does)")
+    if bn.running_mean is None or bn.running_var is None:
+        raise RuntimeError("batch norm without running statistics (track_running_stats=False) cannot be folded")
+    s = (bn.running_var.detach().double() + bn.eps).rsqrt()
+    if bn.weight is not None:
+        s = s * bn.weight.detach().double()
+    w = weight.detach().double() * s.view(-1, *([1] * (weight.dim() - 1)))
+    b = (0.0 if bias is None else bias.detach().double()) - bn.running_mean.detach().double()
+    b = b * s + (0.0 if bn.bias is None else bn.bias.detach().double())
+    return w.float(), b.float()
 
 
-class Conv1d(nn.Module):
-    """1x1 convolution + ReLU over (B, C, N)."""
+class _Affine(nn.Module):
+    """What Conv1d and Linear share: `_sequential` = [affine layer, optional BatchNorm1d] and ReLU behind it."""
+    _sequential: nn.Sequential
+    _output_dim: int
+
+    def output_dim(self) -> int:
+        return self._output_dim
+
+    @property
+    def affine(self):
+        return self._sequential[0]
+
+    @property
+    def norm(self) -> Optional[nn.BatchNorm1d]:
+        return self._sequential[1] if len(self._sequential) > 1 else None
+
+    def folded(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Weight and bias the kernels pack: the layer's own, or with the eval-mode batch norm folded in."""
+        return fold_batch_norm(self.affine.weight, self.affine.bias, self.norm)
+
+    def forward_torch(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's forward, literally (helper.py:37-38,64-65): differentiable, batch statistics in training mode."""
+        return F.relu(self._sequential(x))
+
+
+class Conv1d(_Affine):
+    """1x1 convolution (+ batch norm) + ReLU over (B, C, N)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 1, bias: bool = True,
                  batch_norm: bool = False):
         super().__init__()
-        _no_batch_norm(batch_norm)
         if kernel_size not in (1, (1,)):
             raise NotImplementedError("only kernel_size 1 occurs on the hot path")
         conv = nn.Conv1d(in_channels, out_channels, 1, bias=bias)
         nn.init.xavier_uniform_(conv.weight)
         if conv.bias is not None:
             conv.bias.data.fill_(0.0)
-        self._sequential = nn.Sequential(conv)
+        self._sequential = nn.Sequential(conv, nn.BatchNorm1d(out_channels)) if batch_norm else nn.Sequential(conv)
         self._output_dim = out_channels
 
-    def output_dim(self) -> int:
-        return self._output_dim
 
-    @property
-    def affine(self) -> nn.Conv1d:
-        return self._sequential[0]
-
-
-class Linear(nn.Module):
-    """Fully connected layer + ReLU over (B, C)."""
+class Linear(_Affine):
+    """Fully connected layer (+ batch norm) + ReLU over (B, C)."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True, batch_norm: bool = False):
         super().__init__()
-        _no_batch_norm(batch_norm)
         lin = nn.Linear(in_features, out_features, bias=bias)
         nn.init.xavier_uniform_(lin.weight)
         if bias:
             lin.bias.data.fill_(0.0)
-        self._sequential = nn.Sequential(lin)
+        self._sequential = nn.Sequential(lin, nn.BatchNorm1d(out_features)) if batch_norm else nn.Sequential(lin)
         self._output_dim = out_features
 
-    def output_dim(self) -> int:
-        return self._output_dim
-
-    @property
-    def affine(self) -> nn.Linear:
-        return self._sequential[0]
-
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.fc(x.contiguous(), self.affine.weight, self.affine.bias, act=1)
+        w, b = self.folded()
+        return ops.fc(x.contiguous(), w, b, act=1)
 
 
 class _Stack(nn.Module):
@@ -93,7 +127,18 @@ class _Stack(nn.Module):
         return [m for m in self._sequential if not isinstance(m, nn.Dropout)]
 
     def affine_params(self) -> List[Tuple[torch.Tensor, Optional[torch.Tensor]]]:
-        return [(m.affine.weight, m.affine.bias) for m in self.layers()]
+        """(weight, bias) per layer as the kernels need them: eval-mode batch norm folded in (the parameters themselves
+        where there is none)."""
+        return [m.folded() for m in self.layers()]
+
+    def has_dropout(self) -> bool:
+        return any(isinstance(m, nn.Dropout) for m in self._sequential)
+
+    def forward_torch(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's forward (helper.py:92-93,122-123): every module of `_sequential`, Dropout included, in torch."""
+        for m in self._sequential:
+            x = m(x) if isinstance(m, nn.Dropout) else m.forward_torch(x)
+        return x
 
 
 class Conv1dMultiLayer(_Stack):
@@ -108,28 +153,33 @@ class LinearMultiLayer(_Stack):
         super().__init__(Linear, layer_sizes, batch_norm, dropout_keep, dropout_last)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.training and any(isinstance(m, nn.Dropout) for m in self._sequential):
-            raise NotImplementedError("dropout in training mode is outside the forward-only hot path")
+        if self.training and self.has_dropout():
+            raise RuntimeError("dropout in training mode draws random masks: the inference kernels treat it as the identity "
+                               "(call model.eval(); a training step runs forward_torch)")
         for layer in self.layers():
             x = layer(x)
         return x
 
 
-def _structure_stamp(mods) -> int:
-    """Cheap fingerprint of a module tree's SHAPE: registering a parameter or a submodule anywhere in it changes the
-    count it sums (len() of the per-module dicts: no tensor is touched)."""
-    return sum(len(m._parameters) + len(m._modules) for m in mods)
+def _structure_stamp(dicts):
+    """Fingerprint of a module tree's SHAPE over the (parameters, buffers, children) dicts collected when the slots were
+    built: the IDENTITY of every child and the number of parameters and buffers. Registering a parameter, a buffer or a
+    submodule anywhere changes it, and so does REPLACING a submodule by another of the same arity (`head.output =
+    nn.Linear(...)`: the parent now holds a different object) -- the cached slots would otherwise keep handing out the
+    replaced layer's tensors. No recursive generator: one pass over ~66 dict triples, 13 us."""
+    return [id(c) for _, _, children in dicts for c in children.values()], sum([len(p) + len(b) for p, b, _ in dicts])
 
 
 def flat_parameters(module: nn.Module):
-    """The module's parameters in `parameters()` order without walking the module tree on every call: the (owner dict,
-    name) slots are collected once per module and the CURRENT tensor of each slot is fetched from them, so that replaced
-    parameters (`m.weight = nn.Parameter(...)`), in-place loads and device moves are all seen. The hot paths ask for the
-    weights' versions several times per launch; `parameters()` cost ~0.1 ms each time (23 tensors behind a recursive
-    generator) -- 0.4 ms of host time per dense call + sampling chain, exposed whenever the GPU waits for the host
-    (the first launches of a timed window).
-    The slot list belongs to ONE module object and one tree shape: it records the module it was built for and the
-    tree's structure stamp, and is rebuilt when either differs -- a parameter or submodule registered later is picked
+    """The module's parameters in `parameters()` order, followed by its buffers (batch-norm running statistics: part of
+    what the packed weights are derived from), without walking the module tree through torch's recursive generators on
+    every call: the (owner dict, name) slots are collected once per tree shape and the CURRENT tensor of each slot is
+    fetched from them, so that replaced parameters (`m.weight = nn.Parameter(...)`), in-place loads and device moves are
+    all seen. The hot paths ask for the weights' versions several times per launch; `parameters()` cost ~0.1 ms each time
+    (23 tensors behind a recursive generator) -- 0.4 ms of host time per dense call + sampling chain, exposed whenever the
+    GPU waits for the host (the first launches of a timed window).
+    The slot list belongs to ONE module object and one tree shape: it records the module it was built for and the tree's
+    structure stamp, and is rebuilt when either differs -- a parameter or submodule registered or replaced later is picked
     up, and a replica made by copying `__dict__` (nn.Module._replicate_for_data_parallel, copy.copy) does not key its
     caches on the original's parameters."""
     cached = module.__dict__.get('_dclr_param_slots')
@@ -137,7 +187,9 @@ def flat_parameters(module: nn.Module):
         mods = list(module.modules())
         # every slot, also the ones that hold None now (`register_parameter('bias', None)` filled in later)
         slots = [(m._parameters, name) for m in mods for name in m._parameters]
-        cached = (module, mods, _structure_stamp(mods), slots)
+        slots += [(m._buffers, name) for m in mods for name in m._buffers]
+        dicts = [(m._parameters, m._buffers, m._modules) for m in mods]
+        cached = (module, dicts, _structure_stamp(dicts), slots)
         module.__dict__['_dclr_param_slots'] = cached
     out, seen = [], set()
     for d, n in cached[3]:

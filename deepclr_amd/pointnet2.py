@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from .ops import ball_query, furthest_point_sample  # noqa: F401  (index outputs: nothing to differentiate)
-from .models.helper import PackedCache, flat_parameters
+from .models.helper import PackedCache, flat_parameters, fold_batch_norm
 
 __all__ = ['PointnetSAModuleMSG', 'furthest_point_sample', 'gather_operation', 'ball_query',
            'grouping_operation', 'GatherOperation', 'GroupingOperation']
@@ -70,21 +70,42 @@ grouping_operation = GroupingOperation.apply
 _FUSED_MLP = [16, 16, 32]
 
 
-class _ConvUnit(nn.Sequential):
-    def __init__(self, c_in: int, c_out: int):
+class _BatchNorm2d(nn.Sequential):
+    """The published wrapper (pointnet2 pytorch_utils._BNBase): a module holding the norm layer under the name `bn`
+    (state_dict keys `layerJ.bn.bn.*`), scale 1 and shift 0 at start."""
+
+    def __init__(self, width: int):
         super().__init__()
-        conv = nn.Conv2d(c_in, c_out, kernel_size=(1, 1), bias=True)
+        self.add_module('bn', nn.BatchNorm2d(width))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0)
+
+
+class _ConvUnit(nn.Sequential):
+    """conv -> [batch norm] -> ReLU (published pytorch_utils._ConvBase: with batch norm the conv has no bias)."""
+
+    def __init__(self, c_in: int, c_out: int, bn: bool = False):
+        super().__init__()
+        conv = nn.Conv2d(c_in, c_out, kernel_size=(1, 1), bias=not bn)
         nn.init.kaiming_normal_(conv.weight)
-        nn.init.constant_(conv.bias, 0)
+        if conv.bias is not None:
+            nn.init.constant_(conv.bias, 0)
         self.add_module('conv', conv)
+        if bn:
+            self.add_module('bn', _BatchNorm2d(c_out))
         self.add_module('activation', nn.ReLU(inplace=True))
+
+    def folded(self):
+        """Weight and bias the kernels pack: eval-mode batch norm folded into the conv (models/helper.py)."""
+        norm = self.bn.bn if hasattr(self, 'bn') else None
+        return fold_batch_norm(self.conv.weight, self.conv.bias, norm)
 
 
 class _SharedMLP(nn.Sequential):
-    def __init__(self, spec: List[int]):
+    def __init__(self, spec: List[int], bn: bool = False):
         super().__init__()
         for j in range(len(spec) - 1):
-            self.add_module('layer{}'.format(j), _ConvUnit(spec[j], spec[j + 1]))
+            self.add_module('layer{}'.format(j), _ConvUnit(spec[j], spec[j + 1], bn))
 
 
 class PointnetSAModuleMSG(nn.Module):
@@ -94,9 +115,8 @@ class PointnetSAModuleMSG(nn.Module):
                  bn: bool = True, use_xyz: bool = True, pool_method: str = 'max_pool',
                  instance_norm: bool = False):
         super().__init__()
-        if bn or instance_norm:
-            raise NotImplementedError("normalisation layers are outside the MI355X hot path "
-                                      "(DeepCLR passes bn=batch_norm=False)")
+        if instance_norm:
+            raise NotImplementedError("instance norm is not used by DeepCLR (it passes bn=batch_norm only, deepclr.py:63-70)")
         if not use_xyz or pool_method != 'max_pool':
             raise NotImplementedError("DeepCLR uses use_xyz=True with max pooling")
         if not (len(radii) == len(nsamples) == len(mlps)) or len(radii) < 1:
@@ -116,7 +136,7 @@ class PointnetSAModuleMSG(nn.Module):
             self._in_feat = spec[0]
             self._out.append(spec[-1])
             spec[0] += 3
-            self.mlps.append(_SharedMLP(spec))
+            self.mlps.append(_SharedMLP(spec, bn))
         self.differentiable = False              # True: forward() takes the composed, differentiable path whenever a
                                                  # gradient is wanted, also for shapes the fused kernel covers
         self.fused = fused                       # one-kernel path (csrc/sa.hip); otherwise level-1 operators + dclr_linear
@@ -134,7 +154,7 @@ class PointnetSAModuleMSG(nn.Module):
             return self.packed_mlps_composed()
 
         def build():
-            return [ops.pack_sa_mlp([u.conv.weight for u in stack], [u.conv.bias for u in stack]) for stack in self.mlps]
+            return [ops.pack_sa_mlp(*zip(*[u.folded() for u in stack])) for stack in self.mlps]
         return self._cache.get(flat_parameters(self), build)
 
     def packed_mlps_composed(self):
@@ -145,9 +165,10 @@ class PointnetSAModuleMSG(nn.Module):
             for stack in self.mlps:
                 layers = []
                 for u in stack:
-                    w = u.conv.weight.detach().reshape(u.conv.weight.shape[0], -1)
+                    w, bias = u.folded()
+                    w = w.detach().reshape(w.shape[0], -1)
                     kp = (w.shape[1] + 7) // 8 * 8
-                    layers.append((ops.pack_weight(w, kp), u.conv.bias.detach().contiguous(), w.shape[0], kp))
+                    layers.append((ops.pack_weight(w.contiguous(), kp), bias.detach().contiguous(), w.shape[0], kp))
                 packed.append(layers)
             return packed
         return self._cache_composed.get(flat_parameters(self), build)

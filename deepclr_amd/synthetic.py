@@ -145,9 +145,22 @@ def make_batch(kind: str, n_pairs: int, n_points: int, first_pair: int = 0) -> n
 
 
 def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
-    """Reference state_dict layout for a model-config mapping."""
+    """Reference state_dict layout for a model-config mapping. With `batch_norm: true` every
+    affine layer is followed by a BatchNorm module (/root/reference/deepclr/models/helper.py:27-30,57-60: index 1 of the
+    layer's `_sequential`; set abstraction: the published SharedMLP drops the conv bias and adds `bn.bn`), and with
+    `dropout` < 1 the head's fully connected stack interleaves Dropout modules (helper.py:107-113: the Linear layers then sit
+    at the even indices of its `_sequential`)."""
     prm = cfg['params']
+    bn = bool(prm.get('batch_norm', False))
     shapes: 'OrderedDict[str, Tuple[int, ...]]' = OrderedDict()
+
+    def norm(base: str, width: int) -> None:
+        shapes[base + '.weight'] = (width,)
+        shapes[base + '.bias'] = (width,)
+        shapes[base + '.running_mean'] = (width,)
+        shapes[base + '.running_var'] = (width,)
+        shapes[base + '.num_batches_tracked'] = ()
+
     sa = prm['cloud_features']['params']
     feat_in = cfg['input_dim'] - cfg['point_dim']
     for lv in range(len(sa['mlps'])):            # level 1 specs start with their input width (deepclr.py:61 vs 73)
@@ -155,27 +168,28 @@ def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
         for s, spec in enumerate(sa['mlps'][lv]):
             chans = [feat_in + 3, *spec] if lv == 0 else [spec[0] + 3, *spec[1:]]
             for j in range(len(chans) - 1):
-                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}.conv'.format(lv, s, j)
-                shapes[base + '.weight'] = (chans[j + 1], chans[j], 1, 1)
-                shapes[base + '.bias'] = (chans[j + 1],)
+                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}'.format(lv, s, j)
+                shapes[base + '.conv.weight'] = (chans[j + 1], chans[j], 1, 1)
+                if bn:
+                    norm(base + '.bn.bn', chans[j + 1])
+                else:
+                    shapes[base + '.conv.bias'] = (chans[j + 1],)
             sa_out += spec[-1]
+
+    def stack(prefix: str, chans, conv: bool, step: int = 1) -> None:
+        for j in range(len(chans) - 1):
+            base = '{}._sequential.{}._sequential'.format(prefix, j * step)
+            shapes[base + '.0.weight'] = (chans[j + 1], chans[j], 1) if conv else (chans[j + 1], chans[j])
+            shapes[base + '.0.bias'] = (chans[j + 1],)
+            if bn:
+                norm(base + '.1', chans[j + 1])
+
     me = prm['merge']['params']
-    chans = [3 + (2 if me.get('append_features', True) else 1) * sa_out, *me['mlp']]
-    for j in range(len(me['mlp'])):
-        base = '_merge_layers.0._embedding._conv._sequential.{}._sequential.0'.format(j)
-        shapes[base + '.weight'] = (chans[j + 1], chans[j], 1)
-        shapes[base + '.bias'] = (chans[j + 1],)
+    stack('_merge_layers.0._embedding._conv', [3 + (2 if me.get('append_features', True) else 1) * sa_out, *me['mlp']], True)
     out = prm['output']['params']
-    chans = [3 + me['mlp'][-1], *out['mlp']]
-    for j in range(len(out['mlp'])):
-        base = '_merge_layers.1.conv._sequential.{}._sequential.0'.format(j)
-        shapes[base + '.weight'] = (chans[j + 1], chans[j], 1)
-        shapes[base + '.bias'] = (chans[j + 1],)
+    stack('_merge_layers.1.conv', [3 + me['mlp'][-1], *out['mlp']], True)
     lin = out['linear']
-    for j in range(len(lin) - 1):
-        base = '_merge_layers.1.linear._sequential.{}._sequential.0'.format(j)
-        shapes[base + '.weight'] = (lin[j + 1], lin[j])
-        shapes[base + '.bias'] = (lin[j + 1],)
+    stack('_merge_layers.1.linear', lin, False, step=2 if float(prm.get('dropout', 1.0)) < 1.0 else 1)
     shapes['_merge_layers.1.output.weight'] = (8, lin[-1])
     shapes['_merge_layers.1.output.bias'] = (8,)
     return shapes
@@ -190,6 +204,14 @@ def random_state_dict(cfg: dict, seed: int = 0, bias_scale: float = 0.05) -> Dic
     rng = np.random.default_rng(seed)
     sd: Dict[str, torch.Tensor] = OrderedDict()
     for name, shape in state_dict_shapes(cfg).items():
+        if name.endswith('.num_batches_tracked'):
+            sd[name] = torch.tensor(100, dtype=torch.int64)
+            continue
+        if len(shape) == 1 and not name.endswith('.bias'):
+            # batch-norm scale and running statistics: away from (1, 0, 1) so that a fold that drops a term shows
+            lo, hi = {'weight': (0.5, 1.5), 'running_mean': (-0.3, 0.3), 'running_var': (0.4, 2.5)}[name.rsplit('.', 1)[1]]
+            sd[name] = torch.from_numpy(rng.uniform(lo, hi, size=shape).astype(np.float32))
+            continue
         if name.endswith('.weight'):
             fan_out, fan_in = shape[0], shape[1]
             bound = np.sqrt(6.0 / (fan_in + fan_out))

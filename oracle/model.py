@@ -11,8 +11,10 @@ Restates, in functional form over a reference-layout ``state_dict``:
     (/root/reference/deepclr/models/deepclr.py:30-45, 88-94).
   * ``KnnGrouping`` + ``MotionEmbeddingBase.forward`` (deepclr.py:142-173, 201-231).
   * ``OutputSimple.forward`` + ``_output_activation`` (deepclr.py:275-294).
-  * ``Conv1d``/``Linear`` = affine + ReLU after EVERY layer
-    (/root/reference/deepclr/models/helper.py:37-38, 64-65).
+  * ``Conv1d``/``Linear`` = affine [+ batch norm] + ReLU after EVERY layer
+    (/root/reference/deepclr/models/helper.py:27-38, 57-65); inference (eval mode):
+    batch norm applies its running statistics, dropout (helper.py:77-85,107-113) is
+    the identity and only shifts the layers' indices in the state_dict.
   * ``DeepCLR.forward`` / ``cloud_features`` (deepclr.py:488-521), inference
     branch only (``m is None``, ``y is None``).
 
@@ -37,8 +39,6 @@ class OracleSAModuleMSG(nn.Module):
     def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]],
                  bn: bool = False, use_xyz: bool = True):
         super().__init__()
-        if bn:
-            raise NotImplementedError("oracle restates the bn=False configuration the shipped models use")
         assert len(radii) == len(nsamples) == len(mlps)
         self.npoint, self.radii, self.nsamples, self.use_xyz = npoint, list(radii), list(nsamples), use_xyz
         self.mlps = nn.ModuleList()
@@ -48,18 +48,24 @@ class OracleSAModuleMSG(nn.Module):
                 spec[0] += 3
             stack = nn.Sequential()
             for j in range(len(spec) - 1):
+                # published pytorch_utils.Conv2d: conv (no bias when a norm layer follows) -> [bn.bn] -> ReLU
                 unit = nn.Sequential()
-                conv = nn.Conv2d(spec[j], spec[j + 1], kernel_size=(1, 1), bias=True)
+                conv = nn.Conv2d(spec[j], spec[j + 1], kernel_size=(1, 1), bias=not bn)
                 nn.init.kaiming_normal_(conv.weight)
-                nn.init.constant_(conv.bias, 0)
+                if not bn:
+                    nn.init.constant_(conv.bias, 0)
                 unit.add_module('conv', conv)
+                if bn:
+                    wrap = nn.Sequential()
+                    wrap.add_module('bn', nn.BatchNorm2d(spec[j + 1]))
+                    unit.add_module('bn', wrap)
                 unit.add_module('activation', nn.ReLU(inplace=True))
                 stack.add_module('layer{}'.format(j), unit)
             self.mlps.append(stack)
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None)\
             -> Tuple[torch.Tensor, torch.Tensor]:
-        weights = [[(u.conv.weight, u.conv.bias) for u in stack] for stack in self.mlps]
+        weights = [[(u.conv.weight, u.conv.bias, u.bn.bn if hasattr(u, 'bn') else None) for u in stack] for stack in self.mlps]
         return sa_msg_forward(xyz, features, self.npoint, self.radii, self.nsamples, weights, self.use_xyz)
 
 
@@ -78,17 +84,35 @@ def sa_msg_forward(xyz, features, npoint, radii, nsamples, weights, use_xyz=True
             gf = P.grouping_operation(features.contiguous(), idx)
             grouped = torch.cat([grouped, gf], dim=1) if use_xyz else gf
         h = grouped
-        for w, bias in layers:
-            h = F.relu(F.conv2d(h, w, bias))
+        for w, bias, *norm in layers:                                  # norm: a BatchNorm2d module, a dict of its tensors, or absent
+            h = _batch_norm(F.conv2d(h, w, bias), norm[0] if norm else None)
+            h = F.relu(h)
         outs.append(h.max(dim=3)[0])                                   # max_pool2d over nsample
     return new_xyz, torch.cat(outs, dim=1)
 
 
-def _mlp1d(h: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_layers: int) -> torch.Tensor:
+def _batch_norm(h: torch.Tensor, norm) -> torch.Tensor:
+    """Eval-mode batch norm (running statistics) from a module or from {'weight', 'bias', 'running_mean', 'running_var'}."""
+    if norm is None:
+        return h
+    if isinstance(norm, nn.Module):
+        assert not norm.training, "the oracle restates inference"
+        norm = {'weight': norm.weight, 'bias': norm.bias, 'running_mean': norm.running_mean, 'running_var': norm.running_var}
+    return F.batch_norm(h, norm['running_mean'], norm['running_var'], norm['weight'], norm['bias'], training=False, eps=1e-5)
+
+
+def _norm_of(sd: Dict[str, torch.Tensor], base: str):
+    return {k: sd['{}.{}'.format(base, k)] for k in ('weight', 'bias', 'running_mean', 'running_var')} \
+        if base + '.running_mean' in sd else None
+
+
+def _mlp1d(h: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, n_layers: int, step: int = 1) -> torch.Tensor:
+    """step 2: Dropout modules sit between the layers (identity at inference; the layers keep the even indices)."""
     for j in range(n_layers):
-        w = sd['{}._sequential.{}._sequential.0.weight'.format(prefix, j)]
-        b = sd['{}._sequential.{}._sequential.0.bias'.format(prefix, j)]
-        h = F.relu(F.conv1d(h, w, b)) if w.dim() == 3 else F.relu(F.linear(h, w, b))
+        base = '{}._sequential.{}._sequential'.format(prefix, j * step)
+        w, b = sd[base + '.0.weight'], sd[base + '.0.bias']
+        h = F.conv1d(h, w, b) if w.dim() == 3 else F.linear(h, w, b)
+        h = F.relu(_batch_norm(h, _norm_of(sd, base + '.1')))
     return h
 
 
@@ -99,8 +123,7 @@ class OracleDeepCLR:
         self.cfg = model_cfg
         self.sd = {k: v.detach().to('cpu', torch.float32) for k, v in state_dict.items()}
         prm = model_cfg['params']
-        if prm.get('batch_norm', False):
-            raise NotImplementedError("batch_norm=True is outside the restated path")
+        self.lin_step = 2 if float(prm.get('dropout', 1.0)) < 1.0 else 1     # helper.py:107-113: Dropout behind every Linear
         self.input_dim = int(model_cfg['input_dim'])
         self.point_dim = int(model_cfg['point_dim'])
         sa = prm['cloud_features']['params']
@@ -128,9 +151,10 @@ class OracleDeepCLR:
         xyz = x[:, :3, :].transpose(1, 2).contiguous()
         feats = x[:, 3:, :].contiguous() if x.size(1) > 3 else None
         for lv, level in enumerate(self.sa_levels):                    # deepclr.py:90-93
-            weights = [[(self.sd['_cloud_layers.0._sa{}.mlps.{}.layer{}.conv.weight'.format(lv, s, j)],
-                         self.sd['_cloud_layers.0._sa{}.mlps.{}.layer{}.conv.bias'.format(lv, s, j)])
-                        for j in range(n)] for s, n in enumerate(level['layers'])]
+            def layer(s, j):
+                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}'.format(lv, s, j)
+                return self.sd[base + '.conv.weight'], self.sd.get(base + '.conv.bias'), _norm_of(self.sd, base + '.bn.bn')
+            weights = [[layer(s, j) for j in range(n)] for s, n in enumerate(level['layers'])]
             xyz, feats = sa_msg_forward(xyz, feats, level['npoint'], level['radii'], level['nsamples'], weights)
         return torch.cat((xyz.transpose(1, 2), feats), dim=1)          # (2B, 3+F, npoint)
 
@@ -179,7 +203,7 @@ class OracleDeepCLR:
     # -- deepclr.py:275-294 ---------------------------------------------------------------------
     def pose_head(self, x: torch.Tensor) -> torch.Tensor:
         h = _mlp1d(x, self.sd, '_merge_layers.1.conv', self.head_conv_layers).max(dim=2)[0]
-        h = _mlp1d(h, self.sd, '_merge_layers.1.linear', self.head_lin_layers)
+        h = _mlp1d(h, self.sd, '_merge_layers.1.linear', self.head_lin_layers, self.lin_step)
         y = F.linear(h, self.sd['_merge_layers.1.output.weight'], self.sd['_merge_layers.1.output.bias'])
         y = y.clone()
         if self.label_type == 'POSE3D_QUAT':

@@ -187,6 +187,8 @@ CASES = [
     # configurations no shipped model uses (other widths, k = 40, extra input features, append_features = False)
     ('custom_widths_n512_b2', helpers.custom_widths_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=17), 17, True),
     ('custom_features_n384_b2', helpers.custom_features_cfg, helpers.custom_features_batch, 18, True),
+    # batch norm everywhere (non-trivial running statistics from random_state_dict) + dropout 0.7, eval mode
+    ('small_bn_n512_b2', helpers.small_bn_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=23), 19, True),
 ]
 
 

@@ -21,6 +21,9 @@ GOLDEN_CASES = {
     # (reference deepclr.py:50-70,180-199 accept them; here they run composed from the level-1 HIP operators)
     'custom_widths_n512_b2': ('custom_widths', True),
     'custom_features_n384_b2': ('custom_features', True),
+    # batch_norm: true with non-trivial running statistics and dropout 0.7 (reference helper.py:27-36,57-63,107-113): eval mode,
+    # so the norm layers apply their running statistics (folded into the packed weights here) and dropout is the identity
+    'small_bn_n512_b2': ('small_bn', True),
 }
 
 
@@ -71,6 +74,12 @@ def custom_features_cfg() -> dict:
     return cfg
 
 
+def small_bn_cfg() -> dict:
+    cfg = small_cfg()
+    cfg['params'].update(batch_norm=True, dropout=0.7)
+    return cfg
+
+
 def custom_features_batch(n_pairs: int = 2, n_points: int = 384) -> np.ndarray:
     x = synthetic.make_batch('kitti', n_pairs, n_points, first_pair=21)
     extra = np.random.default_rng(33).uniform(-1.0, 1.0, size=x.shape[:2] + (2,)).astype(np.float32)
@@ -85,6 +94,8 @@ def case_cfg(name: str) -> dict:
         return custom_features_cfg()
     if kind == 'small_global':
         return small_global_cfg()
+    if kind == 'small_bn':
+        return small_bn_cfg()
     if kind == 'small_two_level':
         return small_two_level_cfg()
     return small_cfg() if kind == 'small' else synthetic.model_cfg(kind)

@@ -68,8 +68,7 @@ def test_load_model_config_and_trained_model(tmp_path):
 
 def test_unsupported_configurations_fail_loudly():
     base = synthetic.model_cfg('kitti')
-    for mutate in (lambda c: c['params'].update(batch_norm=True),
-                   lambda c: c['params']['merge']['params'].update(k=65)):      # the kNN search keeps <= 64 neighbours
+    for mutate in (lambda c: c['params']['merge']['params'].update(k=65),):     # the kNN search keeps <= 64 neighbours
         cfg = synthetic.model_cfg('kitti')
         mutate(cfg)
         with pytest.raises(NotImplementedError):
@@ -77,6 +76,9 @@ def test_unsupported_configurations_fail_loudly():
     assert base == synthetic.model_cfg('kitti')
     cfg = synthetic.model_cfg('kitti')
     cfg['params']['merge']['params'].update(k=0)                  # GlobalGrouping (deepclr.py:186-187) is supported
+    assert build_model(model_config_from_dict(cfg)) is not None
+    cfg = synthetic.model_cfg('kitti')
+    cfg['params'].update(batch_norm=True, dropout=0.5)            # norm layers and dropout build since round 5 (eval: folded / identity)
     assert build_model(model_config_from_dict(cfg)) is not None
 
 
@@ -403,3 +405,62 @@ def test_argument_structs_match_the_header_byte_for_byte(tmp_path):
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     m, c = lib.MergeArgs, lib.CloudArgs
     assert got == [ctypes.sizeof(m), m.y.offset, m.overflow.offset, ctypes.sizeof(c), c.f_rows.offset, c.merge.offset]
+
+
+def test_batch_norm_and_dropout_configurations_build_load_and_fold():
+    """`batch_norm: true`, `dropout` < 1 (reference helper.py:27-36,57-63,107-113; deepclr.py:63-70,260-261): the same module
+    tree, hence a strict load of a reference-layout state_dict; in eval mode the running statistics fold into the weights the
+    kernels pack (checked here against torch's own eval-mode modules on the CPU) and dropout is the identity; in training mode
+    the inference entry points refuse."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import helpers
+    from deepclr_amd.models import build_model
+    from deepclr_amd.models.helper import flat_parameters
+    cfg = helpers.small_bn_cfg()
+    sd = synthetic.random_state_dict(cfg, seed=19)
+    model = build_model(model_config_from_dict(cfg))
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd, strict=True)
+    assert not set(model.state_dict()) <= set(synthetic.random_state_dict(helpers.small_cfg(), seed=19))   # really more keys
+    model.eval()
+    head = model._merge_layers[1]
+    assert head.linear.has_dropout() and len(head.linear.layers()) == 2
+    x = torch.randn(3, head.conv.layers()[0].affine.in_channels, 17)
+    h = x
+    for w, b in head.conv.affine_params():
+        h = torch.relu(torch.nn.functional.conv1d(h, w, b))
+    torch.testing.assert_close(h, head.conv.forward_torch(x), rtol=1e-5, atol=1e-6)
+    g = h.max(dim=2)[0]
+    want = head.linear.forward_torch(g)                                   # eval: dropout = identity
+    for w, b in head.linear.affine_params():
+        g = torch.relu(torch.nn.functional.linear(g, w, b))
+    torch.testing.assert_close(g, want, rtol=1e-5, atol=1e-6)
+    unit = model._cloud_layers[0]._sa0.mlps[0].layer0
+    assert unit.conv.bias is None
+    y = torch.randn(2, unit.conv.in_channels, 5, 7)
+    w, b = unit.folded()
+    torch.testing.assert_close(torch.relu(torch.nn.functional.conv2d(y, w, b)), unit(y.clone()), rtol=1e-5, atol=1e-6)
+    # the running statistics are part of what the packed weights depend on: a change must invalidate them
+    key = lambda: tuple((p.data_ptr(), p._version) for p in flat_parameters(head.conv))      # noqa: E731
+    before = key()
+    head.conv.layers()[0].norm.running_mean.add_(0.1)
+    assert key() != before
+    # training mode: batch statistics / random masks -- not what the inference kernels compute
+    model.train()
+    with pytest.raises(RuntimeError, match='RUNNING statistics'):
+        head.conv.affine_params()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='model.eval'):
+        model(torch.zeros(2, 64, 4))
+
+
+def test_replaced_submodule_is_seen_by_the_parameter_slots():
+    """flat_parameters caches (owner dict, name) slots per tree shape; replacing a submodule by one of the same arity must
+    rebuild them (the stamp counted entries only and the packed weights stayed those of the replaced layer)."""
+    from deepclr_amd.models.helper import Conv1d, Conv1dMultiLayer, flat_parameters
+    m = Conv1dMultiLayer([4, 8, 6])
+    old = m._sequential[1]
+    assert any(p is old.affine.weight for p in flat_parameters(m))
+    m._sequential[1] = Conv1d(8, 6)
+    now = flat_parameters(m)
+    assert not any(p is old.affine.weight for p in now) and any(p is m._sequential[1].affine.weight for p in now)
