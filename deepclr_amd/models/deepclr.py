@@ -309,8 +309,11 @@ class MotionEmbeddingBase(nn.Module):
         c_in = d + (2 if self._append_features else 1) * (c - d)
         kp0, n_last = layers[0][3], layers[-1][2]
         out = torch.empty(b, n_last, p0, dtype=torch.float32, device=dev)
-        # template points in chunks that keep the materialised neighbourhood rows below ~256 MB
-        chunk = max(1, min(p0, (1 << 26) // (r * max(kp0, 8) * b)))
+        # template points in chunks that keep the WIDEST materialised row set -- the input rows or any layer's output rows
+        # (ldy of its consumer), two of which are alive at once -- below ~256 MB (a 3-column input in front of a 256-wide
+        # layer is 32 times wider after the first launch than before it)
+        widest = max([kp0, 8] + [layers[j + 1][3] for j in range(len(layers) - 1)])
+        chunk = max(1, min(p0, (1 << 26) // (r * widest * b)))
         for q0 in range(0, p0, chunk):
             q1 = min(p0, q0 + chunk)
             q = q1 - q0
@@ -891,7 +894,7 @@ class DeepCLR(BaseModel):
 
     def _cloud_plan(self, sa0, x: torch.Tensor, per: int, nb: int):
         key = ('cloud', x.device, per, nb, x.shape[1], ops.PRECISION, lib.stream_ptr())
-        plan = self._plans.get(key)
+        plan = self._plan_lookup(key)
         if plan is None or not plan.current():
             merge_plan = self._merge_plan(x, per * nb)
             if merge_plan is None:
@@ -899,10 +902,25 @@ class DeepCLR(BaseModel):
             plan = _CloudPlan.build(sa0, merge_plan, x.device, per, nb, x.shape[1], x.shape[2])
             if plan is None:
                 return None
-            if len(self._plans) > 16:                  # many launch shapes: do not hoard their scratch (plans in use stay
-                self._plans.clear()                    # alive through their callers' references)
-            self._plans[key] = plan
+            self._plan_store(key, plan)
         return plan
+
+    PLAN_CACHE = 48                                    # launch plans kept: (side streams x 2 + dense streams) of a runner, with room
+
+    def _plan_lookup(self, key):
+        plan = self._plans.get(key)
+        if plan is not None:
+            self._plans[key] = self._plans.pop(key)    # most recently used last (dicts keep insertion order)
+        return plan
+
+    def _plan_store(self, key, plan) -> None:
+        """Keep the plan; beyond PLAN_CACHE entries the LEAST recently used one goes (its scratch stays alive while a caller
+        still holds it). Clearing the whole cache, as rounds 3-4 did at 16 entries, made every launch of a runner with more
+        streams than that rebuild its arguments, scratch and output ring inside the timed window."""
+        self._plans.pop(key, None)
+        self._plans[key] = plan
+        while len(self._plans) > self.PLAN_CACHE:
+            self._plans.pop(next(iter(self._plans)))
 
     def plan_cloud_forward(self, x: torch.Tensor, view=None) -> bool:
         """Build now, for the CURRENT stream, what cloud_merge_prep(x, view) would build on its first use there (arguments,
@@ -1014,14 +1032,12 @@ class DeepCLR(BaseModel):
             return None
         # the workspace belongs to one stream: calls enqueued on different streams may run side by side
         key = (f_rows.device, pairs, self.npoint, ops.PRECISION, lib.stream_ptr())
-        plan = self._plans.get(key)
+        plan = self._plan_lookup(key)
         if plan is None or not plan.current():
             plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint, self._range_flag_ptr())
             if plan is None:
                 return None
-            if len(self._plans) > 16:
-                self._plans.clear()
-            self._plans[key] = plan
+            self._plan_store(key, plan)
         return plan
 
     @property

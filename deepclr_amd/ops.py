@@ -209,6 +209,8 @@ def batch_view(batches) -> Optional[Tuple[int, int, int]]:
     first = batches[0]
     if len(batches) < 2 or not first.is_contiguous() or first.dtype != torch.float32 or first.shape[0] % 2:
         return None
+    if first.dim() != 3 or fps_group_layout(first.shape[1]) is None:
+        return None                 # no grouped sampler at this cloud size (n <= 1024, n > 65536): those launches concatenate
     stride = batches[1].data_ptr() - first.data_ptr()
     if stride < 0 or stride % 4 or (0 < stride < first.numel() * 4):
         return None

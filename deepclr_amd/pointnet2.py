@@ -200,7 +200,9 @@ class PointnetSAModuleMSG(nn.Module):
                 raise RuntimeError("clouds of more than {} points are not read in place across batches".format(ops.FUSED_MAX_POINTS))
             xyz = clouds[:, :, :3].contiguous()
             feats = clouds[:, :, 3:].transpose(1, 2).contiguous() if clouds.shape[2] > 3 else None
-            new_xyz, new_feats = self._forward_composed(xyz, feats, train=False)
+            # (a sample computed ahead -- the pipelined runner's sampling stage -- is used, not recomputed: the serial
+            # stage is paid once)
+            new_xyz, new_feats = self._forward_composed(xyz, feats, train=False, idx=None if sample is None else sample[0])
             return ops.channels_to_rows(torch.cat((new_xyz.transpose(1, 2), new_feats), dim=1).contiguous(), ops.F_STRIDE)
         if sample is None:
             sample = self.sample(clouds, view)
@@ -241,11 +243,13 @@ class PointnetSAModuleMSG(nn.Module):
         return ch[:, :3, :].transpose(1, 2).contiguous(), ch[:, 3:, :].contiguous()
 
     def _forward_composed(self, xyz: torch.Tensor, features: Optional[torch.Tensor],
-                          train: Optional[bool] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """The reference's own composition (QueryAndGroup + SharedMLP + max_pool2d) on the level-1 HIP operators."""
+                          train: Optional[bool] = None, idx: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The reference's own composition (QueryAndGroup + SharedMLP + max_pool2d) on the level-1 HIP operators.
+        idx: the furthest-point sample of `xyz` if the caller has it already."""
         xyz = xyz.contiguous()
         b = xyz.shape[0]
-        idx = ops.furthest_point_sample(xyz.detach(), self.npoint)
+        if idx is None:
+            idx = ops.furthest_point_sample(xyz.detach(), self.npoint)
         xyz_t = xyz.transpose(1, 2).contiguous()
         new_xyz_t = gather_operation(xyz_t, idx)                                   # (B, 3, npoint), differentiable
         new_xyz = new_xyz_t.transpose(1, 2).contiguous()
