@@ -265,9 +265,16 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, 
     for (int r0 = blockIdx.y * FC_ROWS; r0 < m; r0 += gridDim.y * FC_ROWS) {
         const int rows = m - r0 < FC_ROWS ? m - r0 : FC_ROWS;
         __syncthreads();
-        for (int r = 0; r < FC_ROWS; ++r)
-            for (int kk = tid; kk < k; kk += FC_WAVES * 64)
-                xs[r][kk] = r < rows ? x[(size_t)(r0 + r) * k + kk] : 0.f;
+        if ((k & 3) == 0 && ((uintptr_t)x & 15) == 0) {              // 16 bytes per lane and request (a quarter of the instructions)
+            for (int r = 0; r < FC_ROWS; ++r)
+                for (int kk = 4 * tid; kk < k; kk += FC_WAVES * 64 * 4)
+                    *reinterpret_cast<float4 *>(&xs[r][kk]) =
+                        r < rows ? *reinterpret_cast<const float4 *>(x + (size_t)(r0 + r) * k + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int r = 0; r < FC_ROWS; ++r)
+                for (int kk = tid; kk < k; kk += FC_WAVES * 64)
+                    xs[r][kk] = r < rows ? x[(size_t)(r0 + r) * k + kk] : 0.f;
+        }
         __syncthreads();
         if (!live) continue;
         float acc[FC_ROWS];
@@ -280,13 +287,35 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, 
                 for (int r = 0; r < FC_ROWS; ++r) acc[r] = fmaf(wv[c], xs[r][c * 64 + lane < k ? c * 64 + lane : 0], acc[r]);
             }
         }
+        // The eight rows' wave sums in ten exchanges instead of 48: the butterfly (xor 32, 16, ..., 1) of fc_wave_sum, but a
+        // lane keeps only half of its rows at each of the first three steps and hands the other half to its partner --
+        // the same pairs are added at every level (a + b == b + a bit for bit), so every row's sum is the one
+        // fc_wave_sum(acc[r]) returns. Afterwards lane 32 b5 + 16 b4 + 8 b3 (+ 0..7) holds row 4 b5 + 2 b4 + b3.
+        static_assert(FC_ROWS == 8, "three halving steps");
+        float h4[4], h2[2], v;
+        {
+            const bool up = (lane & 32) != 0;
 #pragma unroll
-        for (int r = 0; r < FC_ROWS; ++r) {
-            float v = fc_wave_sum(acc[r]) + bv;
+            for (int i = 0; i < 4; ++i) h4[i] = (up ? acc[4 + i] : acc[i]) + __shfl_xor(up ? acc[i] : acc[4 + i], 32);
+        }
+        {
+            const bool up = (lane & 16) != 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) h2[i] = (up ? h4[2 + i] : h4[i]) + __shfl_xor(up ? h4[i] : h4[2 + i], 16);
+        }
+        {
+            const bool up = (lane & 8) != 0;
+            v = (up ? h2[1] : h2[0]) + __shfl_xor(up ? h2[0] : h2[1], 8);
+        }
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        {
+            const int r = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            v += bv;
             if (act == 1) v = fmaxf(v, 0.f);
             else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
             else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
-            if (lane == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
+            if ((lane & 7) == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
         }
     }
 }
