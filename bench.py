@@ -1144,10 +1144,17 @@ SECONDARY_TIMEOUT_S = 150            # per child; a child that fails or overruns
 PLAIN_FLAGS = ('--gpus', '--steps', '--warmup', '--config', '--pose-budget')
 
 
+def under_profiler() -> bool:
+    """rocprofv3 (or another preloaded tool) initialises the GPU inside THIS process before main() runs: such a process must
+    not become the parent of GPU children (the box refuses the exec), so it measures in-process and prints the headline only."""
+    env = os.environ
+    return 'rocprof' in env.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_', 'ROCTRACER')) for k in env)
+
+
 def wants_secondary(args, argv) -> bool:
     """The plain single-GPU c2 invocation (what the driver runs) and nothing else carries the secondary block."""
     flags = [a for a in argv if a.startswith('--')]
-    return (args.gpus == 1 and args.config == 'c2' and not args.no_secondary and 'WORLD_SIZE' not in os.environ
+    return (not under_profiler() and args.gpus == 1 and args.config == 'c2' and not args.no_secondary and 'WORLD_SIZE' not in os.environ
             and os.environ.get('DCLR_BENCH_CHILD') != '1' and all(f.split('=')[0] in PLAIN_FLAGS for f in flags))
 
 

@@ -111,7 +111,8 @@ def run_modes(args, out, py):
     for mode in [m for m in args.modes.split(',') if m]:
         extra = MODES[mode]
         line = os.path.join(out, '{}_bench_{}.json'.format(args.tag, mode))
-        run([py, 'bench.py'] + extra, line)
+        # (the driver's own command carries the `secondary` block; every other line is measured alone)
+        run([py, 'bench.py'] + extra + ([] if mode == 'driver' else ['--no-secondary']), line)
         with open(line) as fh:                                 # keep the JSON line only (stderr chatter goes to the log)
             txt = fh.read()
         rows = [l for l in txt.splitlines() if l.startswith('{')]
@@ -123,7 +124,7 @@ def run_modes(args, out, py):
                   'pose', doc_.get('pose_delta_vs_oracle'), flush=True)
         d = os.path.join(out, 'raw_stats_' + mode)
         run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--', py, 'bench.py'] + extra +
-            ['--no-cpu-baseline', '--no-launch-timer'], os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, mode)))
+            ['--no-cpu-baseline', '--no-launch-timer', '--no-secondary'], os.path.join(out, '{}_{}_bench_under_rocprof.log'.format(args.tag, mode)))
         for path in glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True):
             shutil.copy(path, os.path.join(out, '{}_{}_kernel_stats.csv'.format(args.tag, mode)))
         shutil.rmtree(d, ignore_errors=True)
@@ -175,7 +176,7 @@ def main():
                                       'fetch_factor 2.0 and write_factor 1.0 for 16 B/lane streams'}
         print('calibration:', json.dumps(doc['calibration']), flush=True)
     for cfg in args.configs.split(','):
-        bench = [py, 'bench.py', '--config', cfg, '--no-cpu-baseline'] + BENCH_ARGS[cfg]
+        bench = [py, 'bench.py', '--config', cfg, '--no-cpu-baseline', '--no-secondary'] + BENCH_ARGS[cfg]
         if not args.skip_stats:
             d = os.path.join(out, 'raw_stats_' + cfg)
             run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--'] + bench + ['--no-launch-timer'],

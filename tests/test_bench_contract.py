@@ -205,6 +205,10 @@ def test_secondary_block_is_attached_to_the_plain_single_gpu_line_only(bench, mo
         assert not want(argv), argv
     monkeypatch.setenv('WORLD_SIZE', '1')                  # python -m torch.distributed.run --nproc-per-node 1
     assert not want([])
+    monkeypatch.delenv('WORLD_SIZE')
+    assert want([])
+    monkeypatch.setenv('LD_PRELOAD', '/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so')   # under rocprofv3: the GPU is
+    assert not want([])                                    # initialised in this process already -- no GPU children from it
 
 
 def test_run_with_secondary_prints_one_line_with_every_pass_condensed(bench):
