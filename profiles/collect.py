@@ -175,7 +175,7 @@ def main():
                               'note': 'float4 streaming copy of 256 MiB (> Infinity Cache); MI355X_MICROARCH.md expects '
                                       'fetch_factor 2.0 and write_factor 1.0 for 16 B/lane streams'}
         print('calibration:', json.dumps(doc['calibration']), flush=True)
-    for cfg in args.configs.split(','):
+    for cfg in [c for c in args.configs.split(',') if c]:
         bench = [py, 'bench.py', '--config', cfg, '--no-cpu-baseline', '--no-secondary'] + BENCH_ARGS[cfg]
         if not args.skip_stats:
             d = os.path.join(out, 'raw_stats_' + cfg)
