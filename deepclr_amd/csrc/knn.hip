@@ -103,7 +103,7 @@ __device__ __forceinline__ void knn_block(const Src &cand, size_t cand_cloud, in
             uint32_t lo = 0u, hi = 0xFFFFFFFFu, tau = 0u;
             bool first = true, found = false;
 #pragma unroll 1
-            for (int t = 0; t < 12 && !found; ++t) {
+            for (int t = 0; t < 12 && !found && k <= KNN_LIMIT; ++t) {         // (k > KNN_LIMIT: straight to the k-round selection)
                 const uint64_t pool = __ballot(first || (lmin > lo && lmin < hi));
                 if (pool == 0) break;
                 const uint32_t piv = (uint32_t)__builtin_amdgcn_readlane((int)lmin, __builtin_ctzll(pool));
@@ -266,13 +266,13 @@ struct RowsLauncher {
 extern "C" int dclr_knn(int b, int nx, int ny, int k, const float *x, const float *y, int64_t *row,
                         int64_t *col, dclr_stream_t stream) {
     DCLR_REQUIRE(b > 0 && nx > 0 && ny > 0 && x && y && row && col && b <= 65535);
-    DCLR_REQUIRE(k >= 1 && k <= 64 && nx >= k);
+    DCLR_REQUIRE(k >= 1 && nx >= k);           // (k > 40: the k-round selection; any k up to the candidate count)
     return knn_dispatch<XyzLauncher>(nx, b, nx, ny, k, x, y, row, col, (hipStream_t)stream);
 }
 
 extern "C" int dclr_knn_rows(int pairs, int npoint, int k, const float *f_rows, int32_t *knn_idx,
                              dclr_stream_t stream) {
     DCLR_REQUIRE(pairs > 0 && npoint > 0 && f_rows && knn_idx && pairs <= 65535);
-    DCLR_REQUIRE(k >= 1 && k <= 64 && npoint >= k);
+    DCLR_REQUIRE(k >= 1 && npoint >= k);
     return knn_dispatch<RowsLauncher>(npoint, pairs, npoint, k, f_rows, knn_idx, (hipStream_t)stream);
 }

@@ -139,14 +139,14 @@ class MotionEmbeddingBase(nn.Module):
     def __init__(self, input_dim: int, point_dim: int, k: int, radius: float, mlp: List[int],
                  append_features: bool = True, batch_norm: bool = False, **_kwargs: Any):
         super().__init__()
-        if not 0 <= k <= 64:
-            raise NotImplementedError("the kNN search keeps at most 64 neighbours per query (k <= 64)")
+        if k < 0:
+            raise ValueError("k must be >= 0 (0: every point of the source cloud)")
         if point_dim != 3:
             raise NotImplementedError("three-dimensional points only")
         self._point_dim = point_dim
         self._feat_dim = input_dim - point_dim
         # Row pipeline (fused kernel, rows F -> rows E): the shipped shape -- mlp [128, 128, 256], k <= 32, <= 64 features.
-        # Any other `mlp` / k <= 64 / feature width the reference accepts (deepclr.py:180-199) runs composed from the
+        # Any other `mlp` / k / feature width the reference accepts (deepclr.py:180-199) runs composed from the
         # level-1 HIP operators (forward()).
         self.rows_path = k <= 32 and list(mlp) == [128, 128, 256] and self._feat_dim <= FEAT
         self._append_features = append_features

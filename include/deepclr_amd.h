@@ -92,7 +92,8 @@ int dclr_group_points_grad(int b, int c, int n, int npoints, int nsample, const 
  * DeepCLR builds (/root/reference/deepclr/models/deepclr.py:149-155,164-166).
  * x (b*nx,3) candidates, y (b*ny,3) queries; row, col (b*ny*k) i64: row = global query index,
  * col = global candidate index, each query's k entries contiguous, ascending distance, equal
- * distances in ascending candidate index. Needs 1 <= k <= 64 and nx >= k. */
+ * distances in ascending candidate index. Needs 1 <= k <= nx <= 4096 (k <= 40 takes the rank selection, larger k one
+ * wave arg-min round per neighbour). */
 int dclr_knn(int b, int nx, int ny, int k, const float *x, const float *y, int64_t *row,
              int64_t *col, dclr_stream_t stream);
 

@@ -177,7 +177,7 @@ void dclr_oracle_knn(int b, int nx, int ny, int k, const float *x, const float *
     for (int bi = 0; bi < b; ++bi) {
         for (int qy = 0; qy < ny; ++qy) {
             const size_t gy = (size_t)bi * ny + qy;
-            float dist[64];
+            float dist[4096];                        /* k <= 4096 (the HIP search stages at most 4096 candidates) */
             int64_t *r = row + gy * k, *c = col + gy * k;
             for (int s = 0; s < k; ++s) { dist[s] = 1e10f; c[s] = -1; r[s] = -1; }
             for (int qx = 0; qx < nx; ++qx) {

@@ -112,7 +112,7 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: torch.Tensor, batch_y
     b = int(batch_x.max().item()) + 1 if batch_x.numel() else 0
     assert b == (int(batch_y.max().item()) + 1 if batch_y.numel() else 0)
     nx, ny = x.shape[0] // b, y.shape[0] // b
-    assert nx * b == x.shape[0] and ny * b == y.shape[0] and x.shape[1] == 3 and k <= 64
+    assert nx * b == x.shape[0] and ny * b == y.shape[0] and x.shape[1] == 3 and k <= 4096
     assert torch.equal(batch_x, torch.arange(b).repeat_interleave(nx))
     assert torch.equal(batch_y, torch.arange(b).repeat_interleave(ny))
     row = torch.empty(b * ny * k, dtype=torch.int64)

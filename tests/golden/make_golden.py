@@ -189,6 +189,8 @@ CASES = [
     ('custom_features_n384_b2', helpers.custom_features_cfg, helpers.custom_features_batch, 18, True),
     # batch norm everywhere (non-trivial running statistics from random_state_dict) + dropout 0.7, eval mode
     ('small_bn_n512_b2', helpers.small_bn_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=23), 19, True),
+    # more neighbours than the search's rank selection (and the fused flow kernel) take: k = 70 of 128 source centroids
+    ('small_k70_n512_b2', helpers.small_k70_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=29), 20, True),
 ]
 
 

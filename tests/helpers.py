@@ -24,6 +24,8 @@ GOLDEN_CASES = {
     # batch_norm: true with non-trivial running statistics and dropout 0.7 (reference helper.py:27-36,57-63,107-113): eval mode,
     # so the norm layers apply their running statistics (folded into the packed weights here) and dropout is the identity
     'small_bn_n512_b2': ('small_bn', True),
+    # k = 70 neighbours of 128 source centroids (reference deepclr.py:180-199 takes any k; the search's rank selection stops at 40)
+    'small_k70_n512_b2': ('small_k70', True),
 }
 
 
@@ -80,6 +82,14 @@ def small_bn_cfg() -> dict:
     return cfg
 
 
+def small_k70_cfg() -> dict:
+    cfg = small_cfg()
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'] = [128], [[2.0, 4.0]], [[8, 16]]
+    cfg['params']['merge']['params'].update(k=70, radius=20.0)
+    return cfg
+
+
 def custom_features_batch(n_pairs: int = 2, n_points: int = 384) -> np.ndarray:
     x = synthetic.make_batch('kitti', n_pairs, n_points, first_pair=21)
     extra = np.random.default_rng(33).uniform(-1.0, 1.0, size=x.shape[:2] + (2,)).astype(np.float32)
@@ -96,6 +106,8 @@ def case_cfg(name: str) -> dict:
         return small_global_cfg()
     if kind == 'small_bn':
         return small_bn_cfg()
+    if kind == 'small_k70':
+        return small_k70_cfg()
     if kind == 'small_two_level':
         return small_two_level_cfg()
     return small_cfg() if kind == 'small' else synthetic.model_cfg(kind)

@@ -161,6 +161,8 @@ def test_ball_query_gather_group_bit_exact(kind, b, n, m, radius, nsample):
 @pytest.mark.parametrize('kind,b,nx,ny,k', [
     ('normal', 2, 64, 64, 5), ('kitti', 2, 1024, 1024, 20), ('dup', 2, 512, 512, 30), ('grid', 2, 300, 200, 16),
     ('normal', 1, 3000, 100, 64), ('normal', 3, 100, 257, 7),
+    # more neighbours than the rank selection takes (k > 40) and than round 4 accepted (k > 64): one arg-min round per neighbour
+    ('normal', 2, 300, 50, 100), ('dup', 2, 200, 40, 128), ('grid', 1, 1024, 64, 200), ('kitti', 1, 128, 128, 128),
 ])
 def test_knn_bit_exact(kind, b, nx, ny, k):
     x = _cloud(kind, b, nx, seed=1).reshape(-1, 3)

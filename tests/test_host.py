@@ -68,11 +68,15 @@ def test_load_model_config_and_trained_model(tmp_path):
 
 def test_unsupported_configurations_fail_loudly():
     base = synthetic.model_cfg('kitti')
-    for mutate in (lambda c: c['params']['merge']['params'].update(k=65),):     # the kNN search keeps <= 64 neighbours
+    for mutate, err in ((lambda c: c['params']['merge']['params'].update(k=-1), ValueError),
+                        (lambda c: c.update(point_dim=2, input_dim=3), (NotImplementedError, RuntimeError, AssertionError))):
         cfg = synthetic.model_cfg('kitti')
         mutate(cfg)
-        with pytest.raises(NotImplementedError):
+        with pytest.raises(err):
             build_model(model_config_from_dict(cfg))
+    cfg = synthetic.model_cfg('kitti')
+    cfg['params']['merge']['params'].update(k=100)                # any k builds since round 5 (composed path beyond 32)
+    assert not build_model(model_config_from_dict(cfg))._rows_path
     assert base == synthetic.model_cfg('kitti')
     cfg = synthetic.model_cfg('kitti')
     cfg['params']['merge']['params'].update(k=0)                  # GlobalGrouping (deepclr.py:186-187) is supported
