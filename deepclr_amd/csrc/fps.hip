@@ -1629,7 +1629,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
     __shared__ FpsCand cand[2][16];
     __shared__ unsigned long long wpk[2][16];              // MODE 1: per-wave packed candidate, by round parity
     __shared__ uint32_t wru[2][16];                        // MODE 1: per-wave runner-up value
-    __shared__ float plist[4][4];                          // MODE 1: the samples accepted for the next round
+    __shared__ __attribute__((aligned(16))) float plist[4][4];   // MODE 1: the samples accepted for the next round
     __shared__ int plist_n;
     __shared__ float red[6][16];
     __shared__ uint32_t wsum[16];
@@ -1789,7 +1789,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float l = fps_shfl_min(blo[a]), h = fps_shfl_max(bhi[a]);
-            if (lane == g) { glo[a] = l; ghi[a] = h; }
+            if ((lane & (NG - 1)) == g) { glo[a] = l; ghi[a] = h; }          // (replicated: lane j NG + g tests group g against sample j)
             box[a] = l; box[3 + a] = h;
         }
         if (group_box && lane < 8)
@@ -1799,7 +1799,7 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         vec_set<NG>(gbest, g, any ? 0.f : -1.0f);
         if constexpr (MODE == 1) vec_set<NG>(gsec, g, -1.0f);
         const bool group_any = __ballot(any) != 0;                               // all lanes vote: NOT inside `lane == g &&`
-        if (lane == g && group_any) gmaxv = __uint_as_float(0x7F800000u);        // +inf forces the first update
+        if ((lane & (NG - 1)) == g && group_any) gmaxv = __uint_as_float(0x7F800000u);   // +inf forces the first update
     }
     // every thread re-reads only what it wrote itself (same positions): no further fence needed
 
@@ -1820,7 +1820,10 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
         constexpr int J = FPS_PAGED_J, B = FPS_PAGED_B;
         if (t < 32) { wpk[t >> 4][t & 15] = (unsigned long long)(t & 15); wru[t >> 4][t & 15] = 0u; }
         __syncthreads();
+        static_assert(J * NG <= 64, "one (sample, group) pair per lane in the box tests");
         float pcx[J] = {pts[0]}, pcy[J] = {pts[1]}, pcz[J] = {pts[2]};
+        const int tj = lane / NG;                              // the sample this lane tests its group lane % NG against
+        float tsx = pts[0], tsy = pts[1], tsz = pts[2];
         int np = 1;
         if (t == 0) picked[0] = 0;
         uint32_t gsv = 0u, gkey = 0xFFFFFFFFu;                 // lane g: second-best value bits, tie key of the best point
@@ -1838,14 +1841,19 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             unsigned long long q0, q1, q2, q3, q4, q5;
             FPS_STAMP(q0);
 #endif
+            // All of the round's samples against all of this wave's groups in ONE pass: lane j NG + g tests group g against
+            // sample j (boxes and maxima are replicated over the lane groups). One bound computation per round instead of
+            // one per sample: the kernel is bound by instruction issue (16 waves on 4 SIMDs), and every wave runs this
+            // every round.
             uint32_t act = 0, actj[J];
+            {
+                const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], tsx, tsy, tsz);
+                const unsigned long long hit = __ballot(tj < np && lbv < gmaxv);
 #pragma unroll
-            for (int j = 0; j < J; ++j) {
-                actj[j] = 0u;
-                if (j >= np) continue;                                    // wave-uniform
-                const float lbv = fps_box_lower_bound(glo[0], glo[1], glo[2], ghi[0], ghi[1], ghi[2], pcx[j], pcy[j], pcz[j]);
-                actj[j] = (uint32_t)__ballot(lane < NG && lbv < gmaxv);
-                act |= actj[j];
+                for (int j = 0; j < J; ++j) {
+                    actj[j] = (uint32_t)(hit >> (j * NG)) & ((1u << NG) - 1u);
+                    act |= actj[j];
+                }
             }
 #ifdef FPS_DEBUG
             FPS_STAMP(q1);
@@ -1932,8 +1940,8 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
                         const float wz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bq.z), wl));
                         const int32_t wk = __builtin_amdgcn_readlane(__float_as_int(bq.w), wl);
                         const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+                        if ((lane & (NG - 1)) == g) gmaxv = __uint_as_float(gmx);          // every replica (the box tests read it)
                         if (lane == g) {
-                            gmaxv = __uint_as_float(gmx);
                             gsv = g2;
                             gkey = fps_tk1024((uint32_t)wk);
                             gx = wx; gy = wy; gz = wz; gk = wk;
@@ -1988,6 +1996,10 @@ __global__ __launch_bounds__(1024) void fps_paged_kernel(int n, int pstride, int
             np = plist_n;
 #pragma unroll
             for (int j = 0; j < J; ++j) { pcx[j] = plist[j][0]; pcy[j] = plist[j][1]; pcz[j] = plist[j][2]; }
+            {
+                const float4 ts = *reinterpret_cast<const float4 *>(plist[tj < J ? tj : 0]);
+                tsx = ts.x; tsy = ts.y; tsz = ts.z;
+            }
             r += np;
             sr += 1;
         }
