@@ -1270,6 +1270,47 @@ def test_training_step_gradients_match_the_oracle_autograd(cfg_name):
     _close(y_eval, y_o.detach(), stage=cfg_name + ': eval forward after the training step vs oracle')
 
 
+def test_training_step_with_batch_norm_and_dropout_then_eval_folds_the_updated_statistics():
+    """`batch_norm: true`, `dropout: 0.7` (reference helper.py:27-36,57-63,107-113): a training step runs the torch modules
+    themselves (batch statistics, random masks) on top of the HIP gather / group operators -- every parameter gets a finite
+    gradient and the running statistics move; eval() afterwards folds the UPDATED statistics into the packed weights (the
+    packed-weight caches key on the buffers too) and agrees with the oracle on the updated state_dict; a training-mode
+    forward without gradients is refused instead of silently using running statistics."""
+    from helpers import small_bn_cfg
+    cfg = small_bn_cfg()
+    cfg['params']['loss'] = {'name': 'TransformLoss', 'params': {'p': 2, 'sx': 1.0, 'sq': 10.0}}
+    sd = synthetic.random_state_dict(cfg, seed=31)
+    model = build_model(model_config_from_dict(cfg))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).eval()
+    x = torch.from_numpy(synthetic.make_batch('kitti', 2, 512, first_pair=43))
+    labels = torch.from_numpy(np.stack([LabelType.POSE3D_DUAL_QUAT.from_matrix(synthetic.kitti_like_pair(43 + i, 16)[2])
+                                        for i in range(2)]).astype(np.float32))
+    with torch.no_grad():
+        y_before, _, _ = model(x.to(DEV))
+    _close(y_before, oracle.build_oracle_model(cfg, sd)(x), stage='batch norm model, eval forward before the training step vs oracle')
+    model.train()
+    with torch.no_grad(), pytest.raises(RuntimeError, match='model.eval'):
+        model(x.to(DEV))
+    mean_before = {k: v.clone() for k, v in model.state_dict().items() if k.endswith('running_mean')}
+    torch.manual_seed(0)
+    y_pred, loss, _ = model(x.to(DEV), y=labels.to(DEV))
+    loss.backward()
+    for name, prm in model.named_parameters():
+        if name.startswith('_loss_layer'):
+            continue
+        assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
+    assert any(float(p.grad.abs().max()) > 0 for n, p in model.named_parameters() if n.endswith('_sequential.1.weight'))
+    moved = [k for k, v in model.state_dict().items() if k.endswith('running_mean') and not torch.equal(v, mean_before[k])]
+    assert len(moved) == len(mean_before) and len(moved) >= 10                  # every norm layer saw the batch
+    model.eval()
+    sd_after = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith('_loss_layer')}
+    with torch.no_grad():
+        y_after, _, _ = model(x.to(DEV))
+    assert float((y_after - y_before).abs().max()) > 1e-6                       # the statistics did change the network
+    _close(y_after, oracle.build_oracle_model(cfg, sd_after)(x), stage='batch norm model, eval forward after the training step vs oracle')
+
+
 def test_clouds_beyond_the_fused_kernels_point_limit_run_composed():
     """More than 65536 points per cloud (the fused sampler and set-abstraction kernels index points with 16 bits; a raw
     KITTI scan holds ~120k): the same module composed from the level-1 operators, which take any n -- results against the
