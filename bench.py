@@ -16,7 +16,12 @@ exchange is an RCCL all-gather of the pose outputs.
 per GPU, before this process has touched the GPU) and relays rank 0's JSON line. Rank 0 prints ONE JSON line.
 The CPU oracle is used only for the `cpu_baseline` leg and the pose check -- never inside the timed region.
 
-Lines beside the headline (same schema, `config.mode` says which; profiles/r03_*):
+The plain single-GPU command (`python bench.py [--gpus 1 --steps K --warmup W]`, the driver's) measures the headline window first
+(a child process of its own) and then attaches a `secondary` block: steady state over 200 steps, --strict, ring scans, c4, c5 and
+the single-pair latency, each measured by a further child (pairs/s, ms/step, pose delta max, dominant kernel's roofline fraction);
+`--no-secondary` prints the headline alone. This parent process never touches the GPU.
+
+Lines beside the headline (same schema, `config.mode` says which; profiles/r05_*):
   --strict    one batch of B pairs per sampling launch and per dense launch (no cross-batch fusion)
   --h2d       every step's batch is copied from pinned host memory inside the loop (copy stream, overlapped),
               as the reference does per pair (/root/reference/scripts/inference.py:89-90)
