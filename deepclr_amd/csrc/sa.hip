@@ -129,7 +129,11 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         const bool valid = lane < take;
         const uint32_t e = valid ? sa_ring[wave][s][(head + lane) & (SA_RING - 1)] : 0u;
         const int c = (int)(e >> 16), k = (int)(e & 0xFFFFu);
+#ifdef SA_ABL_GATHER          // timing probe only (wrong rows): the drained entries' points from 64 fixed addresses (cache hits)
+        const float4 p = sa_load_point<C>(cloud, lane);
+#else
         const float4 p = sa_load_point<C>(cloud, k);
+#endif
         *reinterpret_cast<float4 *>(stg + 4 * lane) =
             make_float4(p.x - sa_cxyz[wave][c][0], p.y - sa_cxyz[wave][c][1], p.z - sa_cxyz[wave][c][2], p.w);
         tag[lane] = valid ? c : -1;
