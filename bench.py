@@ -947,6 +947,7 @@ def run(args):
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    mods_before = set(sys.modules) if host_trace is not None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
@@ -964,6 +965,7 @@ def run(args):
         for (fn, line, name), (cc, nc, tt, ct, _) in rows_:
             print('%7.0f us own %7.0f us cum %5d calls  %s:%d %s' % (1e6 * tt, 1e6 * ct, nc, os.path.basename(fn), line, name), file=sys.stderr)
     if host_trace is not None and rank == 0:
+        print('modules imported inside the timed loop: {}'.format(sorted(set(sys.modules) - mods_before)), file=sys.stderr)
         print('host trace (us after t0, per step): ' + ' '.join('%.0f' % (1e6 * v) for v in host_trace) +
               ' | closing fence returned at %.0f' % (1e6 * elapsed), file=sys.stderr)
     ops.TIMER = None

@@ -161,13 +161,24 @@ class LinearMultiLayer(_Stack):
         return x
 
 
-def _structure_stamp(dicts):
-    """Fingerprint of a module tree's SHAPE over the (parameters, buffers, children) dicts collected when the slots were
-    built: the IDENTITY of every child and the number of parameters and buffers. Registering a parameter, a buffer or a
-    submodule anywhere changes it, and so does REPLACING a submodule by another of the same arity (`head.output =
-    nn.Linear(...)`: the parent now holds a different object) -- the cached slots would otherwise keep handing out the
-    replaced layer's tensors. No recursive generator: one pass over ~66 dict triples, 13 us."""
-    return [id(c) for _, _, children in dicts for c in children.values()], sum([len(p) + len(b) for p, b, _ in dicts])
+# Any registration of a submodule, parameter or buffer ANYWHERE in the process bumps this counter (torch's global
+# registration hooks: `m.child = ...`, `seq[i] = ...`, `m.weight = nn.Parameter(...)`, register_buffer, add_module all pass
+# through them). flat_parameters() rebuilds its cached slots when the counter has moved since they were collected --
+# a replaced submodule of the same arity is seen for the price of one integer comparison per call; walking
+# the tree for an identity stamp instead cost 14-19 us per call, ten calls per launch group (0.15 ms of host time at every
+# group boundary of the pipelined runner). Deleting a parameter leaves its slot behind, which then reads None and is
+# skipped; writing a module's private `_modules` / `_parameters` dicts directly is not seen (nothing in torch does).
+_TREE_EPOCH = [0]
+
+
+def _bump_tree_epoch(*_args):
+    _TREE_EPOCH[0] += 1
+    return None                                  # keep the value being registered
+
+
+for _reg in ('register_module_module_registration_hook', 'register_module_parameter_registration_hook',
+             'register_module_buffer_registration_hook'):
+    getattr(torch.nn.modules.module, _reg)(_bump_tree_epoch)
 
 
 def flat_parameters(module: nn.Module):
@@ -178,21 +189,19 @@ def flat_parameters(module: nn.Module):
     all seen. The hot paths ask for the weights' versions several times per launch; `parameters()` cost ~0.1 ms each time
     (23 tensors behind a recursive generator) -- 0.4 ms of host time per dense call + sampling chain, exposed whenever the
     GPU waits for the host (the first launches of a timed window).
-    The slot list belongs to ONE module object and one tree shape: it records the module it was built for and the tree's
-    structure stamp, and is rebuilt when either differs -- a parameter or submodule registered or replaced later is picked
-    up, and a replica made by copying `__dict__` (nn.Module._replicate_for_data_parallel, copy.copy) does not key its
-    caches on the original's parameters."""
+    The slot list belongs to ONE module object and one registration epoch (above): it is rebuilt when a submodule,
+    parameter or buffer has been registered or replaced anywhere since, and a replica made by copying `__dict__`
+    (nn.Module._replicate_for_data_parallel, copy.copy) does not key its caches on the original's parameters."""
     cached = module.__dict__.get('_dclr_param_slots')
-    if cached is None or cached[0] is not module or cached[2] != _structure_stamp(cached[1]):
+    if cached is None or cached[0] is not module or cached[1] != _TREE_EPOCH[0]:
         mods = list(module.modules())
         # every slot, also the ones that hold None now (`register_parameter('bias', None)` filled in later)
         slots = [(m._parameters, name) for m in mods for name in m._parameters]
         slots += [(m._buffers, name) for m in mods for name in m._buffers]
-        dicts = [(m._parameters, m._buffers, m._modules) for m in mods]
-        cached = (module, dicts, _structure_stamp(dicts), slots)
+        cached = (module, _TREE_EPOCH[0], slots)
         module.__dict__['_dclr_param_slots'] = cached
     out, seen = [], set()
-    for d, n in cached[3]:
+    for d, n in cached[2]:
         prm = d.get(n)
         if prm is not None and id(prm) not in seen:                # tied weights are listed once, as parameters() does
             seen.add(id(prm))
