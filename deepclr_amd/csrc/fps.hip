@@ -534,12 +534,28 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
         for (int u = 0; u < BPT; ++u) { hist[BPT * t + u] = run; run += c[u]; }
     }
     __syncthreads();
+    // With the groups exported (group_pts: the sorted point list set abstraction reads -- position p of it IS sorted position
+    // p) every thread writes its points there NOW, from the registers of step 1, at the positions the sort hands out; step 3
+    // then reads each group's points back in order, coalesced and mostly from L2, instead of gathering 16 bytes per point from
+    // all over the cloud by sorted index (64-byte sectors for 16-byte requests: that gather was 190 of the 281 MB a
+    // 160-cloud launch moved, and two dependent round trips of the setup).
+    const bool via_export = group_pts != nullptr;          // wave-uniform
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int k = t + WGS * j;
-        if (k < n) sbuf[atomicAdd(&hist[cellof[k]], 1u)] = (uint16_t)k;
+        if (k < n) {
+            const uint32_t pos = atomicAdd(&hist[cellof[k]], 1u);
+            sbuf[pos] = (uint16_t)k;
+            if (via_export) group_pts[pos] = make_float4(first_x[j], first_y[j], first_z[j], __uint_as_float((uint32_t)k));
+        }
+    }
+    if (via_export) {
+        for (int pos = n + t; pos < NP; pos += WGS)        // padding slots: far away, no index
+            group_pts[pos] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, __uint_as_float(0xFFFFFFFFu));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
     __syncthreads();
+    if (via_export) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef FPS_DEBUG
     if (blockIdx.x == 0 && t == 0) { unsigned long long ts_; FPS_STAMP(ts_); fps_dbg_setup[2] = ts_; }
 #endif
@@ -693,21 +709,20 @@ __global__ __launch_bounds__(WGS) void fps_pruned_kernel(int n, int pstride, int
             float x = 0.f, y = 0.f, z = 0.f, d = -2.0f;   // -2: padding can never beat best = -1
             if (tkg[i] != 0xFFFFu) {
                 const uint32_t k = fps_tk1024_inv(tkg[i]);
-                fps_load_xyz(pts, (size_t)k, pstride, vec4, x, y, z);
+                if (via_export) {                           // sorted position of this slot's point: run run[i] of the group
+                    const float4 v = group_pts[(size_t)deal(g) * (64 * S) + run[i] * 64 + lane];
+                    x = v.x; y = v.y; z = v.z;
+                } else {
+                    fps_load_xyz(pts, (size_t)k, pstride, vec4, x, y, z);
+                }
                 d = temp ? temp[k] : 1e10f;
                 blo[0] = fminf(blo[0], x); blo[1] = fminf(blo[1], y); blo[2] = fminf(blo[2], z);
                 bhi[0] = fmaxf(bhi[0], x); bhi[1] = fmaxf(bhi[1], y); bhi[2] = fmaxf(bhi[2], z);
                 any = true;
             }
             vec_set<P>(px, jj, x); vec_set<P>(py, jj, y); vec_set<P>(pz, jj, z); vec_set<P>(td, jj, d);
-            if (group_pts) {
-                // regrouped copy for the set-abstraction fast path, under the SORTED group's number and in RUN order: slice r
-                // of the exported group = the r-th 64 consecutive sorted positions of the group (their boxes: slice_box)
-                const bool ok = tkg[i] != 0xFFFFu;
-                group_pts[(size_t)deal(g) * (64 * S) + run[i] * 64 + lane] =
-                    make_float4(ok ? x : 3.0e38f, ok ? y : 3.0e38f, ok ? z : 3.0e38f,
-                                __uint_as_float(ok ? fps_tk1024_inv(tkg[i]) : 0xFFFFFFFFu));
-            }
+            // (the regrouped copy for the set-abstraction fast path -- slice r of exported group q = the r-th 64 consecutive
+            // sorted positions of the group, their boxes in slice_box -- was written in step 2, padding included)
         }
         if constexpr (SLICES_IN_STEP3 && S > 1) {
             if (slice_box != nullptr) {                     // wave-uniform: a lane holds one point of each of the S slices (runs)
