@@ -1,3 +1,3 @@
-from deepclr_amd.evaluation import Evaluator, Sequence, load_scenario
+from deepclr_amd.evaluation import Evaluator, MetricsContainer, Sequence, load_scenario
 
-__all__ = ['Evaluator', 'Sequence', 'load_scenario']
+__all__ = ['Evaluator', 'MetricsContainer', 'Sequence', 'load_scenario']

@@ -6,7 +6,8 @@ deepclr/evaluation/{data,metrics,evaluator}.py as a package by path. transforms3
 it is needed only for the euler-angle error *vectors*, which deepclr_amd.evaluation does not provide, so an
 inert placeholder is registered for it (affines.decompose / euler.mat2euler return zeros) and the `vec` fields
 are not exported. What gets pinned: the 26-column result-file format, pose chaining and path lengths, the KITTI
-step errors and the KITTI segment errors.
+step errors and the KITTI segment errors, and the statistics `MetricsContainer` draws from them per sequence and
+over two sequences merged (every field `scripts/evaluation.py:55-78` tabulates except the euler-angle ones).
 
 Usage:  python tests/golden/make_eval_golden.py  [--reference /root/reference]
 """
@@ -47,6 +48,35 @@ def trajectory(n, seed):
     return stamps, pred, gt, times
 
 
+STATS = ('min', 'max', 'mean', 'median', 'std')
+STEP_FIELDS = (('translation', 'kitti'), ('translation', 'rmse'), ('rotation', 'kitti'), ('rotation', 'chordal'))
+SEG_FIELDS = STEP_FIELDS + (('rotation', 'rmse'),)      # the segment `divide` derives it from kitti, no euler angles
+
+
+def container_stats(evaluator, data, seq):
+    """Statistics of the reference's MetricsContainer for sequence 'a' (eval_sequence.txt), a second, shorter drive
+    'b' (eval_sequence_b.txt, written here) and both merged, read through a reference Evaluator."""
+    stamps, pred, gt, times = trajectory(260, seed=12)
+    seq_b = data.Sequence()
+    for s, p, g, t in zip(stamps, pred, gt, times):
+        seq_b.add_transforms(s, p, g, t)
+    seq_b.write(os.path.join(HERE, 'eval_sequence_b.txt'))
+    ev = evaluator.Evaluator()
+    ev._sequences['a'] = seq
+    ev._sequences['b'] = seq_b
+    out = {}
+    groups = (('step', ev.get_step_errors(), ev.get_total_step_errors(), STEP_FIELDS),
+              ('seg', ev.get_segment_errors(), ev.get_total_segment_errors(), SEG_FIELDS))
+    for kind, per_seq, total, fields in groups:
+        for name, cont in list(per_seq.items()) + [('total', total)]:
+            out['{}_{}_count'.format(kind, name)] = np.array(len(cont))
+            for stat in STATS:
+                rec = getattr(cont, stat)
+                row = [getattr(getattr(rec, part), metric) for part, metric in fields] + [rec.time]
+                out['{}_{}_{}'.format(kind, name, stat)] = np.array(row, dtype=np.float64)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference', default='/root/reference')
@@ -84,7 +114,8 @@ def main():
         seg_first=np.array([e.first_frame for e in segs]), seg_length=np.array([e.segment_length for e in segs]),
         seg_speed=np.array([e.speed for e in segs]),
         seg_translation=np.array([e.translation.kitti for e in segs]),
-        seg_rotation=np.array([e.rotation.kitti for e in segs]))
+        seg_rotation=np.array([e.rotation.kitti for e in segs]),
+        **container_stats(evaluator, data, seq))
     print('wrote eval_sequence.txt ({} rows), eval_expected.npz ({} segments)'.format(len(stamps), len(segs)))
 
 

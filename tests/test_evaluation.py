@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from deepclr_amd import evaluation as ev
 
@@ -64,3 +65,199 @@ def test_evaluator_collects_sequences_and_skips_the_stateless_first_frame(tmp_pa
     assert abs(s['step_translation_mean [m]'] - 1.0 / 6) < 1e-12      # five exact pairs, one off by 1 m
     assert abs(s['time_mean [ms]'] - 13.0 / 6) < 1e-12
     assert np.isnan(s['kitti_translation [%]'])                      # 5 m driven: no 100 m segment exists
+
+
+STATS = ('min', 'max', 'mean', 'median', 'std')
+STEP_FIELDS = (('translation', 'kitti'), ('translation', 'rmse'), ('rotation', 'kitti'), ('rotation', 'chordal'))
+SEG_FIELDS = STEP_FIELDS + (('rotation', 'rmse'),)
+
+
+def _two_sequences():
+    e = ev.Evaluator()
+    e.get_sequences()['a'] = ev.Sequence.read(os.path.join(GOLDEN, 'eval_sequence.txt'))
+    e.get_sequences()['b'] = ev.Sequence.read(os.path.join(GOLDEN, 'eval_sequence_b.txt'))
+    return e
+
+
+def test_metrics_container_statistics_match_reference():
+    """min / max / mean / median / std of every field scripts/evaluation.py:55-78 prints, per sequence and merged,
+    against the reference's MetricsContainer (including the segment fields its `divide` derives from kitti)."""
+    want = _expected()
+    e = _two_sequences()
+    groups = (('step', e.get_step_errors(), e.get_total_step_errors(), STEP_FIELDS),
+              ('seg', e.get_segment_errors(), e.get_total_segment_errors(), SEG_FIELDS))
+    for kind, per_seq, total, fields in groups:
+        for name, cont in list(per_seq.items()) + [('total', total)]:
+            assert len(cont) == int(want['{}_{}_count'.format(kind, name)])
+            for stat in STATS:
+                rec = getattr(cont, stat)
+                got = [getattr(getattr(rec, part), metric) for part, metric in fields] + [rec.time]
+                np.testing.assert_allclose(got, want['{}_{}_{}'.format(kind, name, stat)], rtol=2e-6, atol=1e-13,
+                                           err_msg='{} {} {}'.format(kind, name, stat))
+    assert e.get_total_step_errors() is e.get_total_step_errors()            # cached until transforms are added
+    e.add_transforms('b', 0.0, np.eye(4), np.eye(4), 1.0)
+    assert len(e.get_total_step_errors()) == 700 + 260 + 1
+
+
+def test_metrics_container_items_and_empty_case():
+    e = _two_sequences()
+    seg = e.get_segment_errors()['b']
+    item = seg[3]
+    assert item.segment_length == seg.arrays['segment_length'][3] and item.first_frame == seg.arrays['first_frame'][3]
+    assert item.translation.kitti == seg.arrays['translation'][3] and item.time == 0.0
+    assert item.rotation.chordal == item.rotation.kitti / item.segment_length        # metrics.py:104-108
+    assert [x.speed for x in seg] == list(seg.arrays['speed'])
+    step = e.get_step_errors()['b']
+    assert step[-1].time == step.arrays['time'][-1] and step.mean.translation.vec.shape == (3,)
+    with np.testing.assert_raises(IndexError):
+        step[len(step)]
+    short = ev.Evaluator()
+    t = np.eye(4)
+    t[0, 3] = 1.0
+    short.add_transforms('s', 0.0, t, t)
+    empty = short.get_total_segment_errors()
+    assert len(empty) == 0 and np.isnan(empty.mean.translation.kitti) and np.isnan(empty.max.rotation.vec).all()
+
+
+def _euler_to_matrix(angles):
+    out = []
+    for rx, ry, rz in angles:
+        cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+        mx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        my = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        mz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        out.append(mz @ my @ mx)
+    return np.array(out)
+
+
+def test_euler_angles_recompose_and_feed_the_rotation_rmse():
+    """transforms3d is absent (parity unpinned for these fields): the static-xyz angles must rebuild the matrix they
+    came from, also at the pitch singularity, and the per-pair rotation rmse is their rms difference."""
+    rng = np.random.default_rng(5)
+    angles = rng.uniform([-np.pi, -np.pi / 2, -np.pi], [np.pi, np.pi / 2, np.pi], size=(200, 3))
+    np.testing.assert_allclose(ev.euler_sxyz(_euler_to_matrix(angles)), angles, rtol=0, atol=1e-12)
+    gimbal = _euler_to_matrix(np.array([[0.3, np.pi / 2, -0.8], [-1.1, -np.pi / 2, 0.4]]))
+    got = ev.euler_sxyz(gimbal)
+    assert (got[:, 2] == 0).all()
+    np.testing.assert_allclose(_euler_to_matrix(got), gimbal, rtol=0, atol=1e-12)
+    a, b = np.tile(np.eye(4), (3, 1, 1)), np.tile(np.eye(4), (3, 1, 1))
+    a[:, :3, :3] = _euler_to_matrix(np.array([[0.01, 0.02, 0.03], [0, 0, 0.5], [0.2, -0.1, 0.0]]))
+    b[:, :3, :3] = _euler_to_matrix(np.array([[0.00, 0.02, 0.00], [0, 0, 0.1], [0.2, -0.1, 0.0]]))
+    np.testing.assert_allclose(ev.euler_rmse(a, b), np.sqrt(np.array([0.01 ** 2 + 0.03 ** 2, 0.4 ** 2, 0.0]) / 3),
+                               rtol=0, atol=1e-12)
+    seq = ev.Sequence()
+    for i in range(3):
+        seq.add_transforms(i, a[i], b[i])
+    err = ev.step_errors(seq)
+    np.testing.assert_allclose(err['rotation_rmse'], ev.euler_rmse(a, b))
+    # rotation-only error about z: the kitti angle is the yaw difference and its vector carries it on the z slot
+    np.testing.assert_allclose(err['rotation'][1], 0.4, atol=1e-12)
+    np.testing.assert_allclose(np.abs(err['rotation_vec'][1]), [0, 0, 0.4], atol=1e-12)
+
+
+def test_motion_views_and_pose_export(tmp_path):
+    seq = ev.Sequence.read(os.path.join(GOLDEN, 'eval_sequence_b.txt'))
+    m = seq.prediction
+    assert len(m) == 260 and m.poses.shape == (261, 4, 4) and m.get_path().shape == (261, 3)
+    assert np.array_equal(m.poses[0], np.eye(4)) and m.distances[0] == 0
+    f = m.get_frame_by_distance(10, 100)
+    assert m.distances[f] > m.distances[10] + 100 >= m.distances[f - 1]
+    assert m.get_frame_by_distance(10, 1e6) == -1
+    m.write(str(tmp_path / 'poses.txt'), use_poses=True)                  # scripts/export_kitti_poses.py:28-33
+    np.testing.assert_allclose(np.loadtxt(str(tmp_path / 'poses.txt')), m.poses[:, :3, :].reshape(-1, 12))
+
+
+def _write_run(base, name, method, sequential=True):
+    """A run directory as scripts/inference.py leaves it: result files + scenario.yaml with the method filled in."""
+    import yaml
+    d = os.path.join(base, name)
+    os.makedirs(d)
+    e = _two_sequences()
+    e.write(d)
+    with open(os.path.join(d, 'scenario.yaml'), 'w') as f:
+        yaml.safe_dump({'name': 'demo', 'dataset_type': 'GENERIC', 'sequential': sequential,
+                        'data': {'a': '/data/a', 'b': '/data/b'},
+                        'method': {'name': method, 'params': {'model_name': name, 'weights_file': 'w.tar'}}}, f)
+    return d
+
+
+def test_evaluation_flow_of_the_reference_script(tmp_path):
+    """The call sequence of scripts/evaluation.py:83-140 on a run directory written by this build: scenario with
+    method, step / segment tables via the `error.<stat>.<part>.<metric>` attributes, every figure saved."""
+    import matplotlib
+    matplotlib.use('Agg')
+    from deepclr.evaluation import Evaluator, MetricsContainer, load_scenario
+    want = _expected()
+    d = _write_run(str(tmp_path), 'run0', 'DEEPCLR')
+    scenario = load_scenario(os.path.join(d, 'scenario.yaml'), with_method=True)
+    assert scenario.method.name == 'DEEPCLR' and scenario.method.params['model_name'] == 'run0'
+    evaluator = Evaluator.read(d, ['{}.txt'.format(k) for k in scenario.data.keys()])
+    total = evaluator.get_total_segment_errors()
+    assert isinstance(total, MetricsContainer)
+    np.testing.assert_allclose([total.mean.translation.kitti * 100, np.rad2deg(total.mean.rotation.kitti)],
+                               [want['seg_total_mean'][0] * 100, np.rad2deg(want['seg_total_mean'][2])], rtol=2e-6)
+    figures = [evaluator.plot_segment_error_bars(), evaluator.plot_total_kitti_errors()]
+    for group in (evaluator.plot_error_over_time(), evaluator.plot_kitti_errors(), evaluator.plot_sequences(),
+                  evaluator.plot_sequences_2d()):
+        assert list(group) == ['a', 'b']
+        figures.extend(group.values())
+    for i, fig in enumerate(figures):
+        out = tmp_path / 'fig{}.png'.format(i)
+        fig.savefig(str(out), dpi=40)
+        assert out.stat().st_size > 500
+        matplotlib.pyplot.close(fig)
+    from deepclr_amd import plots
+    c = plots.kitti_curves(total)
+    assert list(c['length']) == [100.0, 200.0, 300.0, 400.0, 500.0, 600.0, 700.0, 800.0]
+    a = total.arrays
+    np.testing.assert_allclose(c['by_length'][2, 0], a['translation'][a['segment_length'] == 300].mean())
+    counted = np.nansum([((a['speed'] > lo) & (a['speed'] <= hi)).sum() for lo, hi in
+                         zip(np.linspace(a['speed'].min(), a['speed'].max(), 12)[:-1],
+                             np.linspace(a['speed'].min(), a['speed'].max(), 12)[1:])])
+    assert counted == len(total) - (a['speed'] == a['speed'].min()).sum()
+
+
+REFERENCE_SCRIPT = '/root/reference/scripts/evaluation.py'
+
+
+@pytest.mark.skipif(not os.path.isfile(REFERENCE_SCRIPT), reason="the reference tree exists in the build container only")
+def test_reference_evaluation_script_runs_on_this_builds_output(tmp_path):
+    """f3 end to end: the reference's own scripts/evaluation.py, importing `deepclr` from this repository, evaluates
+    run directories written here (single and multi-run mode) and its CSV columns carry the golden statistics."""
+    import csv
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo, MPLBACKEND='Agg')
+    base = str(tmp_path)
+    _write_run(base, 'run0', 'DEEPCLR')
+    _write_run(base, 'run1', 'DEEPCLR', sequential=False)
+    for argv in ([os.path.join(base, 'run0')], [base, '--scenario', 'demo']):
+        done = subprocess.run([sys.executable, REFERENCE_SCRIPT] + argv, env=env, cwd=base, capture_output=True,
+                              text=True, timeout=600)
+        assert done.returncode == 0, done.stderr[-2000:]
+    want = _expected()
+    out = os.path.join(base, 'run0', 'evaluation')
+    rows = {r['name']: r for r in csv.DictReader(open(os.path.join(out, 'step_errors.csv')))}
+    assert list(rows) == ['a', 'b', 'TOTAL']
+    for name, key in (('a', 'step_a'), ('b', 'step_b'), ('TOTAL', 'step_total')):
+        mean, std, mx = want[key + '_mean'], want[key + '_std'], want[key + '_max']
+        got = rows[name]
+        np.testing.assert_allclose(
+            [float(got['t_kitti_mean [m]']), float(got['t_rmse_std [m]']), float(got['r_kitti_max [deg]']),
+             float(got['r_chordal_mean [deg]']), float(got['time_mean [ms]']), float(got['time_max [ms]'])],
+            [mean[0], std[1], np.rad2deg(mx[2]), np.rad2deg(mean[3]), mean[4], mx[4]], rtol=2e-6)
+    rows = {r['name']: r for r in csv.DictReader(open(os.path.join(out, 'segment_errors.csv')))}
+    mean, std = want['seg_total_mean'], want['seg_total_std']
+    np.testing.assert_allclose(
+        [float(rows['TOTAL']['t_kitti_mean [%]']), float(rows['TOTAL']['r_kitti_std [deg/m]']),
+         float(rows['TOTAL']['r_rmse_mean [deg/m]'])],
+        [mean[0] * 100, np.rad2deg(std[2]), np.rad2deg(mean[4])], rtol=2e-6)
+    for sub in ('segment_errors.png', 'plot_eot/a.pdf', 'plot_error/b.png', 'plot_path/a.png', 'plot_path2d/b.pdf'):
+        assert os.path.getsize(os.path.join(out, sub)) > 1000
+    multi = os.path.join(base, 'evaluation', 'demo')
+    rows = list(csv.DictReader(open(os.path.join(multi, 'demo_step_errors.csv'))))
+    assert [r['name'] for r in rows] == ['run0', 'run1'] and rows[0]['method'] == 'DEEPCLR'
+    assert 'model_name=run1' in rows[1]['params']
+    assert len(list(csv.DictReader(open(os.path.join(multi, 'demo_segment_errors.csv'))))) == 1   # run1: not sequential
+    assert not os.path.isdir(os.path.join(base, 'run1', 'evaluation', 'plot_path'))
