@@ -19,6 +19,7 @@ _i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 SIGNATURES = {
     'dclr_version': [],
     'dclr_error_string': [_i],
+    'dclr_host_device_pointer': [_p, ctypes.POINTER(ctypes.c_void_p)],
     'dclr_furthest_point_sampling': [_i, _i, _i, _p, _p, _p, _p],
     'dclr_gather_points': [_i, _i, _i, _i, _p, _p, _p, _p],
     'dclr_ball_query': [_i, _i, _i, _f, _i, _p, _p, _p, _p],
@@ -151,12 +152,9 @@ class MappedFlag:
     def __init__(self):
         self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.view = self.host.numpy()
-        hip = ctypes.CDLL('libamdhip64.so')
         dev = ctypes.c_void_p()
-        rc = hip.hipHostGetDevicePointer(ctypes.byref(dev), ctypes.c_void_p(self.host.data_ptr()), 0)
-        # (pinned allocations are mapped into the devices' address space at their host address on this platform; the query
-        # is the documented way to ask, the host address the fallback if the runtime does not answer it)
-        self.dev_ptr = dev.value if rc == 0 and dev.value else self.host.data_ptr()
+        check(load().dclr_host_device_pointer(self.host.data_ptr(), ctypes.byref(dev)), 'dclr_host_device_pointer')
+        self.dev_ptr = dev.value
 
     def is_set(self) -> bool:
         return bool(self.view[0])

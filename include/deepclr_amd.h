@@ -37,6 +37,10 @@ typedef void *dclr_stream_t;      /* hipStream_t */
 
 int         dclr_version(void);                 /* 1000*major + minor */
 const char *dclr_error_string(int code);        /* static string, never NULL */
+/* Device address of a page-locked host allocation (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor), asked
+ * of the runtime this library runs on: what a host puts into DclrMergeArgs.overflow to poll the flag without a
+ * device synchronisation. */
+int         dclr_host_device_pointer(void *host, void **device);
 
 /* ------------------------------------------------------------------------------------------
  * Level 1 -- operator-for-operator replacements of the reference's native extension
