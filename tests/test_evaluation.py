@@ -167,7 +167,7 @@ def test_motion_views_and_pose_export(tmp_path):
     np.testing.assert_allclose(np.loadtxt(str(tmp_path / 'poses.txt')), m.poses[:, :3, :].reshape(-1, 12))
 
 
-def _write_run(base, name, method, sequential=True):
+def _write_run(base, name, method, sequential=True, scenario='demo'):
     """A run directory as scripts/inference.py leaves it: result files + scenario.yaml with the method filled in."""
     import yaml
     d = os.path.join(base, name)
@@ -175,7 +175,7 @@ def _write_run(base, name, method, sequential=True):
     e = _two_sequences()
     e.write(d)
     with open(os.path.join(d, 'scenario.yaml'), 'w') as f:
-        yaml.safe_dump({'name': 'demo', 'dataset_type': 'GENERIC', 'sequential': sequential,
+        yaml.safe_dump({'name': scenario, 'dataset_type': 'GENERIC', 'sequential': sequential,
                         'data': {'a': '/data/a', 'b': '/data/b'},
                         'method': {'name': method, 'params': {'model_name': name, 'weights_file': 'w.tar'}}}, f)
     return d
@@ -261,3 +261,27 @@ def test_reference_evaluation_script_runs_on_this_builds_output(tmp_path):
     assert 'model_name=run1' in rows[1]['params']
     assert len(list(csv.DictReader(open(os.path.join(multi, 'demo_segment_errors.csv'))))) == 1   # run1: not sequential
     assert not os.path.isdir(os.path.join(base, 'run1', 'evaluation', 'plot_path'))
+
+
+@pytest.mark.skipif(not os.path.isfile(REFERENCE_SCRIPT), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize('script,scenario,expect', [
+    ('kitti_odometry_table.py', 'kitti_04_10', ('t_rmse [m]', 'r_rmse [deg]', 'Average Inference Time')),
+    ('kitti_artificial_table.py', 'kitti_pairs', ('Rot. Error Mean [deg]', 'Time [ms]')),
+])
+def test_reference_paper_tables_read_this_builds_output(tmp_path, script, scenario, expect):
+    """scripts/paper/*_table.py (the tables of the publication) on a run directory written here: they read
+    `metrics.<stat>.<part>.<metric>` and `.time` off the containers."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = str(tmp_path)
+    _write_run(base, 'run0', 'DEEPCLR', scenario=scenario)
+    done = subprocess.run([sys.executable, os.path.join(os.path.dirname(REFERENCE_SCRIPT), 'paper', script), base],
+                          env=dict(os.environ, PYTHONPATH=repo, MPLBACKEND='Agg'), cwd=base, capture_output=True,
+                          text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    for word in expect:
+        assert word in done.stdout, done.stdout[-1500:]
+    want = _expected()
+    if script == 'kitti_artificial_table.py':                 # one row of totals (pandas elides the middle columns at 80 characters)
+        assert '{:.6f}'.format(np.rad2deg(want['step_total_mean'][3])) in done.stdout
