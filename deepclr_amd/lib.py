@@ -50,6 +50,7 @@ SIGNATURES = {
     'dclr_pack_weight_f16': [_i, _i, _p, _p, _i, _i, _p, _p],
     'dclr_head_conv_fused_f16': [_i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p],
     'dclr_flow_embedding_fused_f16': [_i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dclr_flow_f16_tile': [_i],
     'dclr_merge_forward': [_p, _p, _p],
     'dclr_cloud_forward': [_p, _p, _p, _p],
     'dclr_prepare_cloud_blocks': [_i, _i, _i],

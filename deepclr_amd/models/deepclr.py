@@ -176,7 +176,9 @@ class MotionEmbeddingBase(nn.Module):
                 'wt': ops.pack_weight(w_t.contiguous(), FEAT, kmap), 'ws': ops.pack_weight(w_s.contiguous(), FEAT, kmap),
                 'w2p': ops.pack_weight(w2, 128, tile16=True), 'b2': b2.detach().contiguous(),
                 'w3p': ops.pack_weight(w3, 128, tile16=True), 'b3': b3.detach().contiguous(),
-                'w2h': ops.pack_weight_f16(w2, 128, 16), 'w3h': ops.pack_weight_f16(w3, 128, 16),
+                # the tile the kernel runs this k on (k == 0: slices of 32 neighbours, see forward_rows)
+                'w2h': ops.pack_weight_f16(w2, 128, ops.flow_f16_tile(self._k or 32)),
+                'w3h': ops.pack_weight_f16(w3, 128, ops.flow_f16_tile(self._k or 32)),
             }
         return self._cache.get(flat_parameters(self), build)
 
@@ -205,9 +207,11 @@ class MotionEmbeddingBase(nn.Module):
         # of the maxima within each (post-ReLU values and the 0 of radius-masked rows: the same floor in every slice).
         e_rows = None
         for j0 in range(0, npoint, 32):
-            kc = min(32, npoint - j0)
-            idx = torch.arange(j0, j0 + kc, dtype=torch.int32, device=f_rows.device).view(1, 1, kc) \
-                .expand(pairs, npoint, kc).contiguous()
+            # always 32 slots (one weight packing, ops.flow_f16_tile): a short last slice ends in -1, the search's own
+            # mark for "no neighbour", which the kernels leave out of the maximum
+            col = torch.arange(j0, j0 + 32, dtype=torch.int32, device=f_rows.device)
+            col = torch.where(col < npoint, col, torch.full_like(col, -1))
+            idx = col.view(1, 1, 32).expand(pairs, npoint, 32).contiguous()
             part = embed(idx)
             if e_rows is None:
                 e_rows = part

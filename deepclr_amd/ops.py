@@ -422,6 +422,12 @@ def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torc
     return out
 
 
+def flow_f16_tile(k: int) -> int:
+    """Tile width the library's split-f16 flow kernel wants its layer-2 / layer-3 weights packed with when it runs k
+    neighbours per point (32 from k = 25 up, 16 below; A/B builds force one)."""
+    return int(lib.load().dclr_flow_f16_tile(int(k)))
+
+
 def flow_embedding_fused_f16(f_rows: torch.Tensor, knn_idx: torch.Tensor, pt: torch.Tensor, ps: torch.Tensor,
                              w1a: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
                              w3p: torch.Tensor, b3: torch.Tensor, radius: float) -> torch.Tensor:
