@@ -34,6 +34,7 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -467,7 +468,7 @@ def parse_args(argv=None):
     ap.add_argument('--same-batch', action='store_true',
                     help='feed the SAME resident batch every step (rounds 1-3; scripts/timing.py:27-34 does that too) instead '
                          'of a resident ring of distinct batches: the batches of a grouped launch then alias in memory')
-    ap.add_argument('--pose-budget', type=float, default=20.0,
+    ap.add_argument('--pose-budget', type=float, default=12.0,
                     help='seconds of CPU oracle time for the pose check of the last two launch groups (outside the timed region)')
     ap.add_argument('--pose-pairs', type=int, default=0,
                     help='stop the pose check after this many pairs even if not every batch of the last two groups was covered '
@@ -1126,7 +1127,7 @@ def run(args):
             result['pose_delta_of'] = {'pairs_in_the_checked_groups': available, 'batches_covered': covered,
                                        'batches': len(recent_kept) or 1, 'rank': 0}
             if world == 1 and not args.no_cpu_leg:
-                result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points, budget_s=8.0, pairs_cfg=pairs_cfg)
+                result['cpu_baseline'] = cpu_baseline(cfg, sd, cloud_kind, points, budget_s=6.0, pairs_cfg=pairs_cfg)
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()
@@ -1142,12 +1143,23 @@ def run(args):
 SECONDARY = (
     ('steady_200', ['--config', 'c2', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
     ('strict', ['--config', 'c2', '--strict', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    # plain `model(x)` on the (16, 16384, 4) batch in a loop, one stream, nothing ahead: what a caller of the REFERENCE API gets
+    # at B = 8 (/root/reference/deepclr/models/deepclr.py:488-508; no PipelinedForward)
+    ('serial', ['--config', 'c2', '--no-overlap', '--steps', '100', '--warmup', '10', '--pose-pairs', '4']),
     ('ring', ['--config', 'c2', '--clouds', 'ring', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    ('h2d', ['--config', 'c2', '--h2d', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    # the all-gather path on this one GPU: a one-rank RCCL group, one collective per dense group
+    ('dist1', ['--config', 'c2', '--force-dist', '--steps', '200', '--warmup', '20', '--pose-pairs', '4']),
+    ('sequence', ['--config', 'c2', '--sequence', '--steps', '100', '--warmup', '10', '--pose-pairs', '4']),
     ('c4', ['--config', 'c4', '--pose-pairs', '16']),
     ('c5', ['--config', 'c5', '--pose-pairs', '4']),
+    ('c5_ring', ['--config', 'c5', '--clouds', 'ring', '--pose-pairs', '4']),
     ('latency', ['--config', 'c2', '--latency']),
 )
-SECONDARY_TIMEOUT_S = 150            # per child; a child that fails or overruns is reported as such, the headline stands
+SECONDARY_TIMEOUT_S = 120            # per child; a child that fails or overruns is reported as such, the headline stands
+HEADLINE_TIMEOUT_S = 600
+SECONDARY_DEADLINE_S = 420           # for ALL secondary passes together: past it the remaining ones are skipped (recorded as such),
+                                     # so that headline + secondaries stay inside the driver's limit whatever hangs
 PLAIN_FLAGS = ('--gpus', '--steps', '--warmup', '--config', '--pose-budget')
 
 
@@ -1175,6 +1187,10 @@ def condense(line: dict) -> dict:
            'pose_delta_pairs': line.get('pose_delta_pairs', 1 if 'pose_delta_vs_oracle' in line else 0),
            'dominant_kernel': roof.get('kernel'), 'frac': roof.get('frac'), 'frac_alone': roof.get('frac_alone'),
            'avg_us': roof.get('avg_us'), 'alone_us': roof.get('alone_us')}
+    if line.get('collectives'):
+        out['ranks_seen'], out['collectives'], out['gather_check'] = line.get('ranks_seen'), line['collectives'], line.get('gather_check')
+    if line.get('h2d'):
+        out['h2d'] = line['h2d']
     if 'latency_ms' in line:
         out['latency_ms'] = {k: v.get('median_ms') for k, v in line['latency_ms'].items()}
         out['kernels_us'] = line.get('kernels_us')
@@ -1187,13 +1203,33 @@ def condense(line: dict) -> dict:
     return out
 
 
-def child_line(argv, timeout_s, run=subprocess.run):
-    """One child `bench.py argv` (it initialises the GPU; this process never does). Returns (json line | None, error | None)."""
+def _run_child(cmd, env, timeout_s):
+    """subprocess.run with the child in a process group of its own, killed as a GROUP on timeout (a bench child may have
+    started ranks or helper processes of its own)."""
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        proc.communicate()
+        raise
+    return subprocess.CompletedProcess(cmd, proc.returncode, out, None)
+
+
+def child_line(argv, timeout_s, run=None):
+    """One child `bench.py argv` (it initialises the GPU; this process never does). Returns (json line | None, error | None).
+    run: a stand-in for subprocess.run (tests); None = the process-group runner above."""
     env = dict(os.environ, DCLR_BENCH_CHILD='1')
     t0 = time.time()
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     try:
-        res = run([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=subprocess.PIPE, text=True,
-                  timeout=timeout_s)
+        if run is None:
+            res = _run_child(cmd, env, timeout_s)
+        else:
+            res = run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout_s)
     except subprocess.TimeoutExpired:
         return None, 'timed out after {} s'.format(timeout_s)
     lines = [l for l in (res.stdout or '').splitlines() if l.lstrip().startswith('{')]
@@ -1205,21 +1241,27 @@ def child_line(argv, timeout_s, run=subprocess.run):
         return None, 'unparsable line: {}'.format(exc)
 
 
-def run_with_secondary(argv, run=subprocess.run, plan=SECONDARY, out=sys.stdout) -> int:
+def run_with_secondary(argv, run=None, plan=SECONDARY, out=sys.stdout, deadline_s=SECONDARY_DEADLINE_S, clock=time.time) -> int:
     """Headline first (the unchanged window, a child of its own on the idle chip), then the secondary passes one after
-    another; ONE JSON line = the headline's with `secondary` attached. Any secondary failure is recorded in its slot."""
-    head, err = child_line(list(argv) + ['--no-secondary'], 900, run)
+    another; ONE JSON line = the headline's with `secondary` attached. Any secondary failure is recorded in its slot; once
+    the passes together have used `deadline_s` the remaining ones are skipped, so the line is out in bounded time."""
+    head, err = child_line(list(argv) + ['--no-secondary'], HEADLINE_TIMEOUT_S, run)
     if head is None:
         sys.stderr.write('bench.py: headline run failed: {}\n'.format(err))
         return 1
-    t0 = time.time()
+    sys.stderr.write('bench.py: headline {:.1f} {} measured; secondary passes follow\n'.format(head.get('value', 0.0), head.get('unit', '')))
+    t0 = clock()
     secondary = {}
     for name, extra in plan:
-        line, err = child_line(['--gpus', '1', '--no-secondary', '--no-cpu-leg'] + list(extra), SECONDARY_TIMEOUT_S, run)
+        left = deadline_s - (clock() - t0)
+        if left < 15:
+            secondary[name] = {'error': 'skipped: the secondary passes had used their {} s'.format(deadline_s), 'args': ' '.join(extra)}
+            continue
+        line, err = child_line(['--gpus', '1', '--no-secondary', '--no-cpu-leg'] + list(extra), min(SECONDARY_TIMEOUT_S, left), run)
         secondary[name] = {'error': err, 'args': ' '.join(extra)} if line is None else dict(condense(line), args=' '.join(extra))
     secondary['note'] = ('each entry: a separate process after the headline window, same kernels and inputs policy (resident ring '
                          'of distinct batches), untimed for `value`; pose deltas against the CPU oracle on a few pairs each; '
-                         '{:.0f} s for all of them'.format(time.time() - t0))
+                         '{:.0f} s for all of them'.format(clock() - t0))
     head['secondary'] = secondary
     out.write(json.dumps(head) + '\n')
     out.flush()

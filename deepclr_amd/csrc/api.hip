@@ -1,7 +1,7 @@
 // Library identity, error strings, host-mapped memory.
 #include "common.h"
 
-extern "C" int dclr_version(void) { return 1000 * 0 + 1; }
+extern "C" int dclr_version(void) { return 1000 * 0 + 2; }
 
 extern "C" const char *dclr_error_string(int code) {
     if (code == DCLR_OK) return "ok";

@@ -6,7 +6,7 @@
 #include "common.h"
 
 extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, dclr_stream_t stream) {
-    DCLR_REQUIRE(a != nullptr);
+    DCLR_REQUIRE(a != nullptr && a->struct_size == sizeof(DclrMergeArgs));     // a caller built against another header
     DCLR_REQUIRE(a->pairs > 0 && a->npoint > 0 && a->n_head_layers >= 1 && a->n_head_layers <= DCLR_MERGE_MAX_LAYERS &&
                  a->n_fc >= 1 && a->n_fc <= DCLR_MERGE_MAX_FC && (a->precision == 0 || a->precision == 1) &&
                  a->stages >= 1 && a->stages <= 3);
@@ -77,7 +77,8 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
 // deepclr.py:149-171, which needs nothing but the rows just written).
 extern "C" int dclr_cloud_forward(const DclrCloudArgs *a, void *const *events, void *const *merge_events,
                                   dclr_stream_t stream) {
-    DCLR_REQUIRE(a != nullptr);
+    DCLR_REQUIRE(a != nullptr && a->struct_size == sizeof(DclrCloudArgs));
+    DCLR_REQUIRE(a->merge == nullptr || a->merge->struct_size == sizeof(DclrMergeArgs));
     DCLR_REQUIRE(a->b > 0 && a->n > 0 && a->c >= 3 && a->npoint > 0 && a->n_scales >= 1 && a->n_scales <= DCLR_CLOUD_MAX_SCALES);
     DCLR_REQUIRE(a->clouds && a->fps_idx && a->group_pts && a->group_box && a->f_rows);
     hipStream_t st = (hipStream_t)stream;
@@ -92,9 +93,11 @@ extern "C" int dclr_cloud_forward(const DclrCloudArgs *a, void *const *events, v
                                              a->workspace, a->workspace_bytes, stream);
     if (rc != DCLR_OK) return rc;
     mark();
-    rc = dclr_sa_msg_fused_batched(a->f16, a->b, a->n, a->c, a->npoint, a->clouds, a->pairs_per_batch, a->n_batches,
-                                   a->batch_stride, a->fps_idx, a->n_scales, a->radii, a->nsamples, a->mlp, a->f_rows, nullptr,
-                                   a->group_pts, a->group_box, a->slice_box, stream);
+    // (the split-f16 set-abstraction layers report a clamped activation to the same word as the dense stages)
+    rc = dclr_sa_msg_fused_batched_ov(a->f16, a->b, a->n, a->c, a->npoint, a->clouds, a->pairs_per_batch, a->n_batches,
+                                     a->batch_stride, a->fps_idx, a->n_scales, a->radii, a->nsamples, a->mlp, a->f_rows, nullptr,
+                                     a->group_pts, a->group_box, a->slice_box, a->overflow ? a->overflow : a->merge ? a->merge->overflow : nullptr,
+                                     stream);
     if (rc != DCLR_OK) return rc;
     mark();
     if (a->merge == nullptr) return DCLR_OK;

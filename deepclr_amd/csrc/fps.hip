@@ -200,10 +200,17 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int pstride, in
 
     float td[PR];
     if constexpr (REG_P > 0) {
+        // (branch-free per element: a predicated load per point put 64 branches and 14 spilled registers into this prologue)
+        if (temp) {
 #pragma unroll
-        for (int j = 0; j < PR; ++j) {
-            const int k = t + WGS * j;
-            td[j] = k < n ? (temp ? temp[k] : 1e10f) : -2.0f;
+            for (int j = 0; j < PR; ++j) {
+                const int k = t + WGS * j;
+                const float v = temp[k < n ? k : 0];
+                td[j] = k < n ? v : -2.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PR; ++j) td[j] = t + WGS * j < n ? 1e10f : -2.0f;
         }
     }
     float cx = pts[0], cy = pts[1], cz = pts[2];
@@ -213,9 +220,15 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(int n, int pstride, in
         float best = -1.0f;
         int bk = 0;
         if constexpr (REG_P > 0) {
+            // The points' addresses do not change from round to round: hoisted out of the sampling loop they were 2 REG_P
+            // registers beside the REG_P minima, and at 128 registers per lane the 32- and 64-point forms spilled 252 / 904
+            // bytes. `tr` hides the thread index from that hoisting; eight (64-point form: four) points' loads are in flight at a time.
+            int tr = t;
+            asm volatile("" : "+v"(tr));
 #pragma unroll
             for (int j = 0; j < PR; ++j) {
-                const int k = t + WGS * j;
+                if (j % (REG_P > 32 ? 4 : 8) == 0 && j > 0) __builtin_amdgcn_sched_barrier(0);
+                const int k = tr + WGS * j;
                 const int kc = k < n ? k : 0;
                 const float *p = pts + (size_t)kc * pstride;
                 const float d = dclr_sqdist(p[0], p[1], p[2], cx, cy, cz);

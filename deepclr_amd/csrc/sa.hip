@@ -56,6 +56,7 @@ struct SaParams {
     int n_groups, group_size;
     DclrCloudView view;                         // how the call's clouds lie in memory (dclr_sa_msg_fused_batched)
     const float *slice_box;                     // optional (<= 64 groups of > 64 points): boxes of the groups' 64-point slices
+    uint32_t *overflow;                         // NULL, or the word that receives 1 when a split-f16 activation was clamped
 };
 
 template <int C>
@@ -76,6 +77,7 @@ __shared__ float4 sa_tile[1][SA_TILE];
 __shared__ uint32_t sa_ring[SA_WAVES][SA_MAX_SCALES][SA_RING];
 __shared__ __attribute__((aligned(16))) float sa_obuf[SA_WAVES][64 * 4 + 64];   // drain staging: 64 inputs (float4) + 64 centroid tags
 __shared__ float sa_cxyz[SA_WAVES][SA_CPW][4];
+__shared__ uint32_t *sa_overflow;               // SaParams.overflow, where the out-of-line drain routine finds it
 __shared__ float sa_c16[SA_WAVES * SA_CPW][4];      // the workgroup's 16 centroids (groups path: waves pull them one at a time)
 __shared__ int sa_next;                              // next centroid of the workgroup to be taken
 __shared__ int sa_crowd[SA_WAVES * SA_CPW];          // crowded centroids of the workgroup (redone by the four waves together)
@@ -170,6 +172,7 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         split4(a3[1], a3h[1], a3l[1]);
     }
     uint32_t *acc = &sa_acc[wave][s][0][0];
+    uint64_t clamped = 0;                                                    // lanes that saw an activation beyond the f16 range (F16; scalar registers)
 #ifdef SA_DEBUG
     SA_STAMP(g2);
 #endif
@@ -183,16 +186,18 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         if constexpr (F16) {
             // relu(h1 + b1) as hi / lo halves = the B operand of layer 2 (k = 4 kq + i)
             dclr_h2 p0, q0, p1, q1;
-            dclr_split2_relu(h1[0] + c1[0], h1[1] + c1[1], p0, q0);
-            dclr_split2_relu(h1[2] + c1[2], h1[3] + c1[3], p1, q1);
+            float peak = 0.f;                                                // of this tile only: the kernel has no register to spare
+            dclr_split2_relu(h1[0] + c1[0], h1[1] + c1[1], p0, q0, peak);
+            dclr_split2_relu(h1[2] + c1[2], h1[3] + c1[3], p1, q1, peak);
             const dclr_h4 b1h = {p0[0], p0[1], p1[0], p1[1]}, b1l = {q0[0], q0[1], q1[0], q1[1]};
             dclr_f32x4 x2 = {0.f, 0.f, 0.f, 0.f};
             h2 = dclr_f32x4{c2[0], c2[1], c2[2], c2[3]};                     // the accumulator starts at the bias
             h2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2h, b1h, h2, 0, 0, 0);
             x2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2h, b1l, x2, 0, 0, 0);
             x2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2l, b1h, x2, 0, 0, 0);
-            dclr_split2_relu(fmaf(x2[0], DCLR_SPLIT_INV, h2[0]), fmaf(x2[1], DCLR_SPLIT_INV, h2[1]), p0, q0);
-            dclr_split2_relu(fmaf(x2[2], DCLR_SPLIT_INV, h2[2]), fmaf(x2[3], DCLR_SPLIT_INV, h2[3]), p1, q1);
+            dclr_split2_relu(fmaf(x2[0], DCLR_SPLIT_INV, h2[0]), fmaf(x2[1], DCLR_SPLIT_INV, h2[1]), p0, q0, peak);
+            dclr_split2_relu(fmaf(x2[2], DCLR_SPLIT_INV, h2[2]), fmaf(x2[3], DCLR_SPLIT_INV, h2[3]), p1, q1, peak);
+            clamped |= __ballot(peak > DCLR_F16_MAX);
             const dclr_h4 b2h = {p0[0], p0[1], p1[0], p1[1]}, b2l = {q0[0], q0[1], q1[0], q1[1]};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -270,6 +275,9 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
         fold(t, ha);
     }
     flush();
+    if constexpr (F16) {
+        if (clamped != 0) dclr_report_overflow(sa_overflow, 2.f * DCLR_F16_MAX);     // the LDS word is read only then
+    }
 #ifdef SA_DEBUG
     SA_STAMP(g3);
     if (lane == 0) { sa_dbg_l[wave][0] += g1 - g0; sa_dbg_l[wave][1] += g3 - g2; }
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(SA_WAVES * 64, 4) void sa_msg_kernel(SaParams prm,
         const float4 q = sa_load_point<C>(cloud, fps_idx[bi * prm.npoint + jc]);
         sa_c16[tid][0] = q.x; sa_c16[tid][1] = q.y; sa_c16[tid][2] = q.z; sa_c16[tid][3] = 0.f;
     }
-    if (tid == 0) { sa_next = 0; sa_ncrowd = 0; }
+    if (tid == 0) { sa_next = 0; sa_ncrowd = 0; sa_overflow = prm.overflow; }
     int cnt[SA_CPW][SA_MAX_SCALES];
     int jrow[SA_CPW];                                                // centroid (row) index of slot c, -1: slot unused
     const int n_live = prm.npoint - j0 < SA_CPW ? (prm.npoint - j0 > 0 ? prm.npoint - j0 : 0) : SA_CPW;
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(256) void channels_to_rows_kernel(int npoint, int n
 static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clouds, const int32_t *fps_idx, int n_scales,
                      const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs, float *out_rows,
                      int32_t *counts, const float *group_pts, const float *group_box, dclr_stream_t stream,
-                     DclrCloudView view = DclrCloudView{0, 1, 0}, const float *slice_box = nullptr) {
+                     DclrCloudView view = DclrCloudView{0, 1, 0}, const float *slice_box = nullptr, uint32_t *overflow = nullptr) {
     DCLR_REQUIRE(b > 0 && n > 0 && npoint > 0 && clouds && fps_idx && radii_host && nsamples_host &&
                  mlp_host_ptrs && out_rows && b <= 65535);
     if (n_scales < 1 || n_scales > SA_MAX_SCALES || (c != 3 && c != 4)) return DCLR_E_UNSUPPORTED;
@@ -971,6 +979,7 @@ static int sa_launch(bool f16, int b, int n, int c, int npoint, const float *clo
     SaParams prm{};
     prm.n = n; prm.npoint = npoint; prm.n_scales = n_scales;
     prm.view = view;
+    prm.overflow = overflow;
     for (int s = 0; s < n_scales; ++s) {
         DCLR_REQUIRE(nsamples_host[s] > 0 && mlp_host_ptrs[s]);
         prm.radius2[s] = radii_host[s] * radii_host[s];
@@ -1037,9 +1046,21 @@ extern "C" int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoin
                                          const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
                                          const float *group_pts, const float *group_box, const float *slice_box,
                                          dclr_stream_t stream) {
+    return dclr_sa_msg_fused_batched_ov(f16, b, n, c, npoint, clouds, pairs_per_batch, n_batches, batch_stride, fps_idx, n_scales,
+                                        radii_host, nsamples_host, mlp_host_ptrs, out_rows, counts, group_pts, group_box,
+                                        slice_box, nullptr, stream);
+}
+
+extern "C" int dclr_sa_msg_fused_batched_ov(int f16, int b, int n, int c, int npoint, const float *clouds,
+                                            int pairs_per_batch, int n_batches, long long batch_stride, const int32_t *fps_idx,
+                                            int n_scales, const float *radii_host, const int *nsamples_host,
+                                            const float *const *mlp_host_ptrs, float *out_rows, int32_t *counts,
+                                            const float *group_pts, const float *group_box, const float *slice_box,
+                                            uint32_t *overflow, dclr_stream_t stream) {
     DCLR_REQUIRE(pairs_per_batch > 0 && n_batches > 0 && batch_stride >= 0 && b == 2 * pairs_per_batch * n_batches);
     return sa_launch(f16 != 0, b, n, c, npoint, clouds, fps_idx, n_scales, radii_host, nsamples_host, mlp_host_ptrs, out_rows,
-                     counts, group_pts, group_box, stream, DclrCloudView{pairs_per_batch, n_batches, batch_stride}, slice_box);
+                     counts, group_pts, group_box, stream, DclrCloudView{pairs_per_batch, n_batches, batch_stride}, slice_box,
+                     overflow);
 }
 
 extern "C" int dclr_rows_to_channels(int b, int npoint, int nfeat, int xyz_col, int stride, const float *rows,

@@ -31,8 +31,10 @@ def local_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 
 def gather_outputs(y_local: torch.Tensor, n_pairs: int) -> torch.Tensor:
-    """All-gather per-rank outputs (B_local, D) into (n_pairs, D), in global pair order, on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    """All-gather per-rank outputs (B_local, D) into (n_pairs, D), in global pair order, on every rank. With a process
+    group of ONE rank the collective still runs (a copy through RCCL: what `bench.py --force-dist` and the one-GPU RCCL test
+    exercise); without a process group the outputs are returned as they are."""
+    if not dist.is_initialized():
         return y_local
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = [pair_range(n_pairs, r, world) for r in range(world)]

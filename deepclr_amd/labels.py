@@ -5,8 +5,12 @@ Host-side mirror of ``LabelType`` (/root/reference/deepclr/data/labels.py:10-101
 ``to_matrix`` (78-101) and ``from_matrix`` (53-76) for the quaternion label
 types. The reference delegates quaternion algebra to transforms3d==0.3.1, which
 is not in this image; the few closed-form helpers needed are written out here
-in numpy float64. POSE3D_EULER needs transforms3d's euler conventions and is
-not used by any shipped model -> NotImplementedError.
+in numpy float64 -- including, since round 6, the static-xyz euler pair of
+POSE3D_EULER (labels.py:54-58, 82-86; degrees in the label): **parity
+unpinned** (no transforms3d here, no fixture in the reference tree), checked
+by recomposition and against the dual-quaternion branch in tests/test_host.py.
+`affines.decompose` (which also strips scale and shear) is the identity split
+on the rigid transforms this path produces and is restated as such.
 """
 from enum import auto
 from typing import List, Optional, Tuple
@@ -51,6 +55,25 @@ def _qmult(a: np.ndarray, b: np.ndarray) -> np.ndarray:
                      w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2])
 
 
+def _euler2mat_sxyz(roll: float, pitch: float, yaw: float) -> np.ndarray:
+    """transforms3d.euler.euler2mat(roll, pitch, yaw, axes='sxyz'): rotations about the STATIC x, then y, then z axes,
+    R = Rz(yaw) Ry(pitch) Rx(roll); radians."""
+    ci, si, cj, sj, ck, sk = np.cos(roll), np.sin(roll), np.cos(pitch), np.sin(pitch), np.cos(yaw), np.sin(yaw)
+    return np.array([[cj * ck, si * sj * ck - ci * sk, ci * sj * ck + si * sk],
+                     [cj * sk, si * sj * sk + ci * ck, ci * sj * sk - si * ck],
+                     [-sj, si * cj, ci * cj]])
+
+
+def _mat2euler_sxyz(r: np.ndarray) -> Tuple[float, float, float]:
+    """transforms3d.euler.mat2euler(R, axes='sxyz'): (roll, pitch, yaw) in radians; at the pitch = +-90 deg singularity yaw
+    is 0 and roll takes the rest, as that library does (deepclr_amd/evaluation.py euler_sxyz is the batched twin)."""
+    r = np.asarray(r, dtype=np.float64)
+    cy = np.hypot(r[0, 0], r[1, 0])
+    if cy > 4.0 * _EPS64:
+        return float(np.arctan2(r[2, 1], r[2, 2])), float(np.arctan2(-r[2, 0], cy)), float(np.arctan2(r[1, 0], r[0, 0]))
+    return float(np.arctan2(-r[1, 2], r[1, 1])), float(np.arctan2(-r[2, 0], cy)), 0.0
+
+
 class LabelType(ConfigEnum):
     POSE3D_EULER = auto()
     POSE3D_QUAT = auto()
@@ -85,6 +108,11 @@ class LabelType(ConfigEnum):
         label = np.asarray(label, dtype=np.float64)
         if scale is not None:
             label = label / scale
+        if self == LabelType.POSE3D_EULER:                   # reference labels.py:82-86: angles in degrees
+            m = np.eye(4)
+            m[:3, :3] = _euler2mat_sxyz(*np.deg2rad(label[3:6]))
+            m[:3, 3] = label[:3]
+            return m
         if self == LabelType.POSE3D_QUAT:
             m = np.eye(4)
             m[:3, :3] = _quat2mat(label[3:])
@@ -102,7 +130,10 @@ class LabelType(ConfigEnum):
     def from_matrix(self, data: np.ndarray, scale: Optional[float] = None) -> np.ndarray:
         data = np.asarray(data, dtype=np.float64)
         t, r = data[:3, 3], data[:3, :3]
-        if self == LabelType.POSE3D_QUAT:
+        if self == LabelType.POSE3D_EULER:                   # reference labels.py:54-58
+            roll, pitch, yaw = _mat2euler_sxyz(r)
+            label = np.array([t[0], t[1], t[2], np.rad2deg(roll), np.rad2deg(pitch), np.rad2deg(yaw)])
+        elif self == LabelType.POSE3D_QUAT:
             q = _mat2quat(r)
             label = np.array([t[0], t[1], t[2], q[0], q[1], q[2], q[3]])
         elif self == LabelType.POSE3D_DUAL_QUAT:

@@ -37,6 +37,7 @@ SIGNATURES = {
     'dclr_sa_msg_fused_f16': [_i, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_fps_clouds_grouped_batched': [_i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _p, _p, _p, _p, ctypes.c_longlong, _p],
     'dclr_sa_msg_fused_batched': [_i, _i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'dclr_sa_msg_fused_batched_ov': [_i, _i, _i, _i, _i, _p, _i, _i, ctypes.c_longlong, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'dclr_rows_to_channels': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_channels_to_rows': [_i, _i, _i, _i, _i, _p, _p, _p],
     'dclr_pack_weight': [_i, _i, _p, _p, _i, _i, _p, _p],
@@ -64,6 +65,7 @@ MERGE_EVENTS = 6 + MERGE_MAX_FC
 class MergeArgs(ctypes.Structure):
     """DclrMergeArgs (include/deepclr_amd.h)."""
     _fields_ = [
+        ('struct_size', ctypes.c_uint32),
         ('pairs', _i), ('npoint', _i), ('k', _i), ('precision', _i), ('stages', _i), ('radius', _f),
         ('n_head_layers', _i), ('head_k_in', _i), ('n_fc', _i),
         ('head_k', _i * MERGE_MAX_LAYERS), ('head_n', _i * MERGE_MAX_LAYERS),
@@ -75,6 +77,10 @@ class MergeArgs(ctypes.Structure):
         ('overflow', _p),
     ]
 
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(type(self))
+
 
 CLOUD_MAX_SCALES, CLOUD_EVENTS = 4, 3
 
@@ -82,12 +88,17 @@ CLOUD_MAX_SCALES, CLOUD_EVENTS = 4, 3
 class CloudArgs(ctypes.Structure):
     """DclrCloudArgs (include/deepclr_amd.h)."""
     _fields_ = [
+        ('struct_size', ctypes.c_uint32),
         ('b', _i), ('n', _i), ('c', _i), ('npoint', _i), ('pairs_per_batch', _i), ('n_batches', _i),
         ('batch_stride', ctypes.c_longlong), ('f16', _i), ('n_scales', _i),
         ('radii', _f * CLOUD_MAX_SCALES), ('nsamples', _i * CLOUD_MAX_SCALES), ('mlp', _p * CLOUD_MAX_SCALES),
         ('clouds', _p), ('fps_idx', _p), ('group_pts', _p), ('group_box', _p), ('slice_box', _p),
-        ('workspace', _p), ('workspace_bytes', ctypes.c_longlong), ('f_rows', _p), ('merge', _p),
+        ('workspace', _p), ('workspace_bytes', ctypes.c_longlong), ('f_rows', _p), ('merge', _p), ('overflow', _p),
     ]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(type(self))
 
 
 _lib: Optional[ctypes.CDLL] = None

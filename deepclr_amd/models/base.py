@@ -58,6 +58,16 @@ class ModelInferenceHelper:
     def reset_state(self) -> None:
         self._state = None
 
+    def finish(self) -> None:
+        """Wait for the model's work in flight and raise if any of it left the range of the split-f16 matrix path (its
+        poses are wrong: deepclr_amd.models.DeepCLR.check_range). Every predict* method ends with it, so that the result
+        it hands out -- the last or only one of a run included -- is never a silently clamped one; the reference's
+        scripts read each result on the host right away (scripts/inference.py:104-107, timing.py:41-44), which waits for
+        the same work. Models without such a check (the reference interface has none): a no-op."""
+        check = getattr(self._model, 'check_range', None)
+        if check is not None:
+            check(synchronize=True)
+
     def _fit_columns(self, cloud: torch.Tensor, which: str) -> torch.Tensor:
         cols = cloud.shape[1]
         if cols < self._input_dim:
@@ -84,11 +94,13 @@ class ModelInferenceHelper:
                 if previous is None:
                     return None
                 y, _, _ = self._model.forward(self.stack(previous, feat), is_feat=True)
+                self.finish()
                 return y[0, :]
 
             if template is None:
                 raise RuntimeError("Source and template clouds are required for non-sequential prediction.")
             y, _, _ = self._model.forward(self.stack(template, source), is_feat=False)
+            self.finish()
             return y[0, :]
 
     def predict_batch(self, sources: torch.Tensor, templates: torch.Tensor) -> torch.Tensor:
@@ -100,6 +112,7 @@ class ModelInferenceHelper:
         with torch.no_grad():
             x = torch.cat((templates[:, :, :self._input_dim], sources[:, :, :self._input_dim]), dim=0)
             y, _, _ = self._model.forward(x.contiguous(), is_feat=False)
+        self.finish()
         return y
 
     def predict_sequence(self, frames: torch.Tensor) -> torch.Tensor:
@@ -118,6 +131,7 @@ class ModelInferenceHelper:
             if feats.shape[0] < 2:
                 return feats.new_empty(0, getattr(self._model, 'label_dim', 0))
             y, _, _ = self._model.forward(torch.cat((feats[:-1], feats[1:])), is_feat=True)
+        self.finish()
         return y
 
     @staticmethod

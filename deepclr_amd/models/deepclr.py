@@ -860,6 +860,9 @@ class DeepCLR(BaseModel):
 
     def cloud_feature_rows(self, x: torch.Tensor, sample=None, view=None) -> torch.Tensor:
         """(2B, N, C) -> rows F ((2B)*npoint, 68); sample: precomputed self.sample(x), else computed here."""
+        sa0 = getattr(self._cloud_layers[0], '_sa0', None)
+        if sa0 is not None and x.is_cuda:
+            sa0.overflow_ptr = self._range_flag_ptr()      # the split-f16 set-abstraction layers report a clamp there too
         return self._cloud_layers[0].forward_rows(x, sample, view)
 
     def merge_prep(self, f_rows: torch.Tensor, pairs: int):

@@ -167,7 +167,8 @@ class LinearMultiLayer(_Stack):
 # a replaced submodule of the same arity is seen for the price of one integer comparison per call; walking
 # the tree for an identity stamp instead cost 14-19 us per call, ten calls per launch group (0.15 ms of host time at every
 # group boundary of the pipelined runner). Deleting a parameter leaves its slot behind, which then reads None and is
-# skipped; writing a module's private `_modules` / `_parameters` dicts directly is not seen (nothing in torch does).
+# skipped; deleting a SUBMODULE is caught by a child count (flat_parameters); writing a module's private `_parameters`
+# dict directly is not seen (nothing in torch does).
 _TREE_EPOCH = [0]
 
 
@@ -193,12 +194,15 @@ def flat_parameters(module: nn.Module):
     parameter or buffer has been registered or replaced anywhere since, and a replica made by copying `__dict__`
     (nn.Module._replicate_for_data_parallel, copy.copy) does not key its caches on the original's parameters."""
     cached = module.__dict__.get('_dclr_param_slots')
-    if cached is None or cached[0] is not module or cached[1] != _TREE_EPOCH[0]:
+    # REMOVING a submodule (del seq[i], Sequential.pop, delattr) fires no registration hook: the child count over the
+    # cached module list is the structural term that catches it (one len() per module, ~2 us; ADVICE r05)
+    if cached is None or cached[0] is not module or cached[1] != _TREE_EPOCH[0] \
+            or cached[4] != sum(len(m._modules) for m in cached[3]):
         mods = list(module.modules())
         # every slot, also the ones that hold None now (`register_parameter('bias', None)` filled in later)
         slots = [(m._parameters, name) for m in mods for name in m._parameters]
         slots += [(m._buffers, name) for m in mods for name in m._buffers]
-        cached = (module, _TREE_EPOCH[0], slots)
+        cached = (module, _TREE_EPOCH[0], slots, mods, sum(len(m._modules) for m in mods))
         module.__dict__['_dclr_param_slots'] = cached
     out, seen = [], set()
     for d, n in cached[2]:

@@ -275,11 +275,13 @@ def pack_sa_mlp(weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor])
 
 def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[float], nsamples: Sequence[int],
                  mlps: List[torch.Tensor], want_counts: bool = False, groups=None, precision: Optional[str] = None,
-                 view: Optional[Tuple[int, int, int]] = None):
+                 view: Optional[Tuple[int, int, int]] = None, overflow: Optional[int] = None):
     """clouds (B,N,C), fps_idx (B,npoint) -> rows F (B*npoint, 68) [, counts (B,npoint,scales)].
     groups: (group_pts, group_box[, slice_box]) from fps_clouds_grouped for the same clouds, or None.
     precision: 'f16x2' (layers 2, 3 of the shared MLP on split-f16 operands) or 'f32'; default ops.PRECISION.
-    view: as fps_clouds_grouped (clouds = the first batch, fps_idx / groups cover all batches)."""
+    view: as fps_clouds_grouped (clouds = the first batch, fps_idx / groups cover all batches).
+    overflow: device address of the word the split-f16 layers set when an activation is clamped (lib.MappedFlag.dev_ptr;
+    an even number of clouds only -- the entry that takes it is the batched one)."""
     clouds = lib.dev_f32(clouds, 'clouds')
     b, n, c = clouds.shape
     if view is not None:
@@ -294,15 +296,15 @@ def sa_msg_fused(clouds: torch.Tensor, fps_idx: torch.Tensor, radii: Sequence[fl
     nsamp_h = (ctypes.c_int * ns)(*[int(s) for s in nsamples])
     mlp_h = (ctypes.c_void_p * ns)(*[lib.dev_f32(m, 'mlp').data_ptr() for m in mlps])
     sbox = groups[2] if groups is not None and len(groups) > 2 else None
-    if view is None and sbox is not None and b % 2 == 0:
+    if view is None and (sbox is not None or overflow is not None) and b % 2 == 0:
         view = (b // 2, 1, 0)                                     # the batched entry with one batch = the plain call
     if view is not None:
-        _call('dclr_sa_msg_fused_batched', 'sa_msg_fused[%dx%d]' % (b, n), int((precision or PRECISION) == 'f16x2'), b, n, c,
+        _call('dclr_sa_msg_fused_batched_ov', 'sa_msg_fused[%dx%d]' % (b, n), int((precision or PRECISION) == 'f16x2'), b, n, c,
               npoint, clouds.data_ptr(), view[0], view[1], view[2], fps_idx.data_ptr(), ns,
               ctypes.cast(radii_h, ctypes.c_void_p), ctypes.cast(nsamp_h, ctypes.c_void_p),
               ctypes.cast(mlp_h, ctypes.c_void_p), out.data_ptr(), lib.ptr(counts),
               None if groups is None else groups[0].data_ptr(), None if groups is None else groups[1].data_ptr(),
-              lib.ptr(sbox), lib.stream_ptr())
+              lib.ptr(sbox), overflow, lib.stream_ptr())
         return (out, counts) if want_counts else out
     entry = 'dclr_sa_msg_fused_f16' if (precision or PRECISION) == 'f16x2' else 'dclr_sa_msg_fused'
     _call(entry, 'sa_msg_fused[%dx%d]' % (b, n), b, n, c, npoint, clouds.data_ptr(), fps_idx.data_ptr(), ns,

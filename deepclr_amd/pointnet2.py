@@ -143,6 +143,7 @@ class PointnetSAModuleMSG(nn.Module):
         self._cache = PackedCache()
         self._cache_composed = PackedCache()
         self._range_ok = None                    # weights key of the last checked split-f16 pass (ops.CHECK_RANGE)
+        self.overflow_ptr = None                 # device address of the owning model's range flag (lib.MappedFlag), or None
 
     def out_features(self) -> int:
         return sum(self._out)
@@ -209,7 +210,8 @@ class PointnetSAModuleMSG(nn.Module):
         idx, gpts, gbox = sample[:3]
         groups = None if gpts is None else (gpts, gbox) + tuple(sample[3:4])      # (+ slice boxes where the sampler exports them)
         mlps = self.packed_mlps()
-        rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, view=view)
+        rows = ops.sa_msg_fused(clouds, idx, self.radii, self.nsamples, mlps, groups=groups, view=view,
+                                overflow=self.overflow_ptr if ops.PRECISION == 'f16x2' else None)
         if ops.PRECISION == 'f16x2' and ops.CHECK_RANGE != 'never':
             # split-f16 operands clamp at +-65504: the first call after the weights changed (or every call with
             # CHECK_RANGE = 'always') also runs the f32 matrix instructions and compares (two host syncs, once)

@@ -7,7 +7,12 @@
  *   - plain pointers + sizes, no torch types; every pointer is DEVICE memory
  *     unless its name ends in _host;
  *   - the caller allocates every output and workspace; the library never
- *     allocates, never synchronises and keeps no global state (re-entrant);
+ *     synchronises and keeps no global state (re-entrant). It allocates in
+ *     ONE place: dclr_furthest_point_sampling, whose signature (the
+ *     reference's) has no workspace argument, takes the scratch of the
+ *     16385..65536-point kernel from the stream-ordered allocator
+ *     (hipMallocAsync / hipFreeAsync on `stream`); every other entry point,
+ *     dclr_fps_clouds_ws / _grouped_ws included, works in caller memory only;
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued
  *     asynchronously on it, exactly like the reference's wrappers enqueue on
  *     at::cuda::getCurrentCUDAStream() (/root/reference/extern/pointnet2.patch:113,155,285,317);
@@ -35,7 +40,9 @@ extern "C" {
 
 typedef void *dclr_stream_t;      /* hipStream_t */
 
-int         dclr_version(void);                 /* 1000*major + minor */
+int         dclr_version(void);                 /* 1000*major + minor. 0.2: DclrMergeArgs / DclrCloudArgs start with
+                                                 * struct_size and carry `overflow`; dclr_flow_embedding_fused_f16 reads the
+                                                 * weight packing dclr_flow_f16_tile(k) names; dclr_knn takes any k */
 const char *dclr_error_string(int code);        /* static string, never NULL */
 /* Device address of a page-locked host allocation (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor), asked
  * of the runtime this library runs on: what a host puts into DclrMergeArgs.overflow to poll the flag without a
@@ -273,6 +280,13 @@ int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const fl
                               const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs,
                               float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
                               const float *slice_box, dclr_stream_t stream);
+/* The same with the word the split-f16 layers (f16 != 0) set to 1 when an activation exceeds 65504 and is clamped
+ * (NULL: not reported; semantics of DclrMergeArgs.overflow below). ABI 0.2. */
+int dclr_sa_msg_fused_batched_ov(int f16, int b, int n, int c, int npoint, const float *clouds, int pairs_per_batch,
+                                 int n_batches, long long batch_stride, const int32_t *fps_idx, int n_scales,
+                                 const float *radii_host, const int *nsamples_host, const float *const *mlp_host_ptrs,
+                                 float *out_rows, int32_t *counts, const float *group_pts, const float *group_box,
+                                 const float *slice_box, uint32_t *overflow, dclr_stream_t stream);
 /* slice_box (optional, groups of more than 64 points, n <= 16384): (b, n_groups * group_size / 64, 8) f32, the boxes
  * (min xyz, max xyz, 0, 0) of the 64-point slices of every exported group -- a group's points are exported slice by slice,
  * slice r = the r-th 64 consecutive points of the spatially sorted cloud inside the group. Set abstraction tests a
@@ -294,6 +308,9 @@ int dclr_sa_msg_fused_batched(int f16, int b, int n, int c, int npoint, const fl
 #define DCLR_MERGE_MAX_FC 4
 #define DCLR_MERGE_EVENTS (6 + DCLR_MERGE_MAX_FC)
 typedef struct DclrMergeArgs {
+    uint32_t struct_size;                   /* sizeof(DclrMergeArgs) of the header the caller was built against: a call with
+                                             * another size is rejected (DCLR_E_INVALID) instead of being read past its end
+                                             * (ABI 0.2; 0.1 had no such member and no `overflow`) */
     int pairs, npoint, k, precision;        /* precision: 0 = f32 matrix path, 1 = split-fp16 (f16x2) */
     int stages;                             /* bit 0: layer-1 halves + kNN (fill pt, ps, knn_idx); bit 1: flow embedding,
                                              * head, fully connected tail (consume them); 3 = everything */
@@ -336,6 +353,7 @@ int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stre
 #define DCLR_CLOUD_MAX_SCALES 4
 #define DCLR_CLOUD_EVENTS 3
 typedef struct DclrCloudArgs {
+    uint32_t struct_size;                   /* sizeof(DclrCloudArgs), checked like DclrMergeArgs.struct_size */
     int b, n, c, npoint;                    /* clouds of the call (all batches), points per cloud, columns, samples */
     int pairs_per_batch, n_batches;         /* as dclr_fps_clouds_grouped_batched: b == 2 * pairs_per_batch * n_batches */
     long long batch_stride;
@@ -350,6 +368,8 @@ typedef struct DclrCloudArgs {
     long long workspace_bytes;
     float *f_rows;                          /* out */
     const DclrMergeArgs *merge;             /* optional: stage 1 of dclr_merge_forward on f_rows (pairs = b / 2) */
+    uint32_t *overflow;                     /* as DclrMergeArgs.overflow, for the split-f16 set-abstraction layers (f16 != 0);
+                                             * NULL: merge->overflow when `merge` is given, else not reported */
 } DclrCloudArgs;
 int dclr_cloud_forward(const DclrCloudArgs *args, void *const *events, void *const *merge_events, dclr_stream_t stream);
 

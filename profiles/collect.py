@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 # (the f32-matrix-path kernels run once, in the range-checked first forward: they get span names of their own so that their
 # counters are not averaged into the split-f16 kernels' -- a default build times the split-f16 kernels)
 KERNEL_TO_SPAN = [('fps_', 'fps_clouds'), ('sa_msg_kernel', 'sa_msg_fused'), ('knn_rows_kernel', 'knn_rows'),
-                  ('flow16_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding_f32'),
+                  ('flow16_kernel', 'flow_embedding'), ('flow32_kernel', 'flow_embedding'), ('flow_kernel', 'flow_embedding_f32'),
                   ('head16', 'head_conv_fused'), ('head_fused_kernel', 'head_conv_fused_f32'),
                   ('linear_kernel', 'linear_pair'), ('fc_kernel', 'fc')]
 # enough steps for several grouped launches of every kind in steady state (c2: 10 batches per launch, c5: 20), so that

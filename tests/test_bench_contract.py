@@ -224,7 +224,16 @@ def test_run_with_secondary_prints_one_line_with_every_pass_condensed(bench):
         assert env['DCLR_BENCH_CHILD'] == '1'
         if '--strict' in argv:
             return types.SimpleNamespace(returncode=3, stdout='')
-        if '--latency' in argv:
+        if '--force-dist' in argv:
+            line = {'value': 43000.0, 'unit': 'scan-pairs/s', 'ms_per_step': 0.186, 'steps': 200, 'warmup': 20,
+                    'config': {'mode': 'grouped', 'workload': 'w'}, 'pose_delta_vs_oracle': 1e-6, 'roofline': None,
+                    'ranks_seen': [0], 'collectives': {'all_gathers': 20, 'steps_per_all_gather': 10, 'bytes_per_rank': 2560},
+                    'gather_check': {'checked': 20, 'ok': True}}
+        elif '--h2d' in argv:
+            line = {'value': 40000.0, 'unit': 'scan-pairs/s', 'ms_per_step': 0.2, 'steps': 200, 'warmup': 20,
+                    'config': {'mode': 'grouped', 'workload': 'w'}, 'pose_delta_vs_oracle': 1e-6, 'roofline': None,
+                    'h2d': {'bytes_per_step': 4194304.0, 'gb_per_s': 21.0, 'batches_per_copy': 2}}
+        elif '--latency' in argv:
             line = {'value': 1234.0, 'unit': 'scan-pairs/s', 'ms_per_step': 0.81, 'steps': 20, 'warmup': 5,
                     'config': {'mode': 'latency', 'workload': 'one pair'}, 'pose_delta_vs_oracle': 1.5e-6,
                     'latency_ms': {'pairwise': {'median_ms': 0.81}, 'sequential': {'median_ms': 0.79}}, 'kernels_us': {'fps': 650.0},
@@ -248,7 +257,14 @@ def test_run_with_secondary_prints_one_line_with_every_pass_condensed(bench):
     assert doc['value'] == 40001.0 and doc['steps'] == 20                                       # the headline's own figures
     sec = doc['secondary']
     assert set(sec) == {n for n, _ in bench.SECONDARY} | {'note'}
-    assert {'steady_200', 'strict', 'ring', 'c4', 'c5'} <= set(sec)
+    # round 6: the reference API's own loop (`serial`), host-fed batches, the sequence workload, c5 on
+    # ring scans and the one-rank RCCL pass are driver-observed too
+    assert {'steady_200', 'strict', 'serial', 'ring', 'h2d', 'dist1', 'sequence', 'c4', 'c5', 'c5_ring', 'latency'} == set(sec) - {'note'}
+    by_name = dict(bench.SECONDARY)
+    assert '--no-overlap' in by_name['serial'] and '--force-dist' in by_name['dist1'] and '--sequence' in by_name['sequence']
+    assert by_name['c5_ring'][:4] == ['--config', 'c5', '--clouds', 'ring'] and '--h2d' in by_name['h2d']
+    assert sec['dist1']['ranks_seen'] == [0] and sec['dist1']['collectives']['all_gathers'] == 20 and sec['dist1']['gather_check']['ok']
+    assert sec['h2d']['h2d']['gb_per_s'] == 21.0
     assert sec['strict']['error'].startswith('exit code 3') and '--strict' in sec['strict']['args']
     for name in ('steady_200', 'ring', 'c4', 'c5'):
         e = sec[name]
@@ -256,6 +272,26 @@ def test_run_with_secondary_prints_one_line_with_every_pass_condensed(bench):
         assert e['dominant_kernel'] == 'head_conv_fused[80x1024]' and e['frac'] == 0.2 and e['frac_alone'] == 0.44
         assert e['sampler']['alone_us'] == 700.0 and e['latency_ms_per_batch_median'] == 9.6
     assert sec['latency']['latency_ms'] == {'pairwise': 0.81, 'sequential': 0.79} and sec['latency']['pose_delta_max'] == 1.5e-6
+    # the passes share ONE deadline -- once it is used up the remaining ones are skipped and the line still goes out
+    now = [0.0]
+
+    def slow_run(cmd, env=None, stdout=None, text=None, timeout=None):
+        now[0] += 100.0                                                  # every child takes 100 s of the fake clock
+        assert timeout is not None and timeout <= bench.HEADLINE_TIMEOUT_S
+        return fake_run(cmd, env=env)
+    out2 = io.StringIO()
+    assert bench.run_with_secondary([], run=slow_run, out=out2, deadline_s=250, clock=lambda: now[0]) == 0
+    sec2 = json.loads(out2.getvalue())['secondary']
+    ran = [n for n, _ in bench.SECONDARY if 'skipped' not in str(sec2[n].get('error'))]
+    assert ran == [n for n, _ in bench.SECONDARY][:3] and all('skipped' in sec2[n]['error'] for n, _ in bench.SECONDARY[3:])
+    assert bench.HEADLINE_TIMEOUT_S + bench.SECONDARY_DEADLINE_S + 120 < 1500           # inside the driver's limit whatever hangs
+    # the real child runner: its own process group, killed as a group on timeout
+    import subprocess
+    import sys
+    with pytest.raises(subprocess.TimeoutExpired):
+        bench._run_child([sys.executable, '-c', 'import time; time.sleep(30)'], dict(os.environ), 0.5)
+    res = bench._run_child([sys.executable, '-c', 'print("{}")'], dict(os.environ), 30)
+    assert res.returncode == 0 and res.stdout.strip() == '{}'
     # a failing headline is a failing run
     assert bench.run_with_secondary([], run=lambda *a, **k: types.SimpleNamespace(returncode=1, stdout=''), out=io.StringIO()) == 1
 

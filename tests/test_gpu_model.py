@@ -13,7 +13,7 @@ import torch
 
 import oracle
 from oracle import labels as olabels
-from deepclr_amd import ops, synthetic
+from deepclr_amd import lib, ops, synthetic
 from deepclr_amd.config import model_config_from_dict
 from deepclr_amd.labels import LabelType
 from deepclr_amd.models import build_model, ModelInferenceHelper
@@ -849,6 +849,40 @@ def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_orac
             assert torch.equal(y_feat, y)
         else:
             _close(feat, orc.cloud_features(moved), stage='m path: cloud_features vs oracle on the transformed clouds')
+
+
+def test_inference_helper_reports_a_clamped_last_forward():
+    """the sticky range flag used to be read only on the NEXT entry into the model, so the last (or only)
+    forward of a run could hand out clamped poses silently. Every predict* method of the helper now ends with
+    finish() = check_range(synchronize=True); and the split-f16 set-abstraction layers report their clamps to the same
+    word (they used to clamp silently: only flow embedding and head were tracked)."""
+    cfg = synthetic.model_cfg('kitti')
+    sd = synthetic.random_state_dict(cfg, seed=4)
+    model, _ = _models(cfg, sd)
+    helper = ModelInferenceHelper(model)
+    x = torch.from_numpy(synthetic.make_batch('kitti', 2, 2048, first_pair=30)).to(DEV)
+    y_ok = helper.predict_batch(x[2:], x[:2]).clone()                    # first forward of the checkpoint: checked in f32, passes
+    assert not model._range_unchecked()
+    hot = x.clone()
+    hot[:, :, 3] *= 1.0e9                                                # intensities ~1e9: set abstraction layer 1 leaves the range
+    with pytest.raises(RuntimeError, match='DCLR_PRECISION=f32'):
+        helper.predict_batch(hot[2:], hot[:2])                           # ONE call, nothing after it: raises, no pose handed out
+    _close(helper.predict_batch(x[2:], x[:2]), y_ok.cpu(), stage='in-range batch after the reported one')
+    with pytest.raises(RuntimeError, match='DCLR_PRECISION=f32'):
+        helper.predict(hot[2], hot[0])                                   # the reference scripts' call pattern
+    assert helper.predict(x[2], x[0]) is not None
+    # the set-abstraction kernel by itself sets the word it is given
+    flag = lib.MappedFlag()
+    sam = model._cloud_layers[0]._sa0
+    fps = ops.fps_clouds(hot, sam.npoint)
+    ops.sa_msg_fused(hot, fps, sam.radii, sam.nsamples, sam.packed_mlps(), precision='f16x2', overflow=flag.dev_ptr)
+    torch.cuda.synchronize()
+    assert flag.is_set()
+    flag.clear()
+    ops.sa_msg_fused(x, ops.fps_clouds(x, sam.npoint), sam.radii, sam.nsamples, sam.packed_mlps(), precision='f16x2',
+                     overflow=flag.dev_ptr)
+    torch.cuda.synchronize()
+    assert not flag.is_set()
 
 
 def test_split_f16_range_guard(monkeypatch):
