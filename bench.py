@@ -453,6 +453,10 @@ def parse_args(argv=None):
     ap.add_argument('--dense-group', type=int, default=None, choices=[0, 1],
                     help='1: the dense stages (flow embedding, head, FC tail) of the batches sampled together also run '
                          'as one launch sequence over group x B pairs')
+    ap.add_argument('--eager-dense', type=int, default=None, choices=[0, 1],
+                    help='dense groups: 1 = enqueue a group\'s dense stages right behind its sampling launch (round 6 experiment: '
+                         'slower, 40.8k against 42.6k in the 20-step window), 0 / default = at the step that hands out the '
+                         'group\'s first batch')
     ap.add_argument('--strict', action='store_true',
                     help='no cross-batch fusion: --group 1 --dense-group 0 (every launch covers ONE batch of B pairs; '
                          'sampling still runs `depth` batches ahead on side streams)')
@@ -762,6 +766,8 @@ def run(args):
         runner = None if args.no_overlap else PipelinedForward(model, depth=args.depth, ahead=args.ahead,
                                                                group=args.group, dense_group=dense_group,
                                                                dense_streams=1 if dense_group else args.dense_streams,
+                                                               eager_dense=(None if args.eager_dense is None else
+                                                                            bool(args.eager_dense) and dense_group),
                                                                inputs_ready=True)   # resident and never rewritten, or
                                                                                     # ordered by the feeder's copy events
     if args.h2d:
@@ -1089,7 +1095,9 @@ def run(args):
                                                                 args.group, 'ahead': args.ahead,
                                                                 'dense_streams': len(getattr(runner, '_dense_streams', [])) or 1,
                                                                 'batches_per_dense_launch':
-                                                                args.group if getattr(runner, '_dense_group', False) else 1}},
+                                                                args.group if getattr(runner, '_dense_group', False) else 1,
+                                                                'dense_enqueued': 'behind the sampling launch' if getattr(
+                                                                    runner, '_eager', False) else 'at the group\'s first step'}},
             'ranks_seen': ranks_seen,
             'host_cores_of_rank0': None if not pinned else '{}-{} ({} of the {} this node grants, one disjoint slice per rank)'.format(
                 pinned[0], pinned[-1], len(pinned), len(pinned) * int(os.environ.get('LOCAL_WORLD_SIZE', world))),

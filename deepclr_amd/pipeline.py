@@ -19,7 +19,8 @@ from .models.deepclr import DeepCLR
 
 class PipelinedForward:
     def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1,
-                 dense_group: bool = False, inputs_ready: bool = False, dense_streams: int = 1):
+                 dense_group: bool = False, inputs_ready: bool = False, dense_streams: int = 1,
+                 eager_dense: Optional[bool] = None):
         """ahead: what runs on the side streams -- 'sample' (sampling only), 'features' (sampling + set
         abstraction; the dense kernels of two batches then overlap and fill each other's tails) or 'knn' (also
         the kNN search and the per-point halves of flow layer 1, which need nothing but the feature rows; the
@@ -44,7 +45,17 @@ class PipelinedForward:
         batch's dense stages are six dependent launches (flow embedding, clear, head, three fully connected layers), 0.25-
         0.37 ms under contention for 8 KITTI pairs: on ONE stream that chain, not the sampler, sets the pace of the un-fused
         regime (bench.py --strict). The caller's stream waits for each batch's outputs (an event), so results are ordered
-        for the caller exactly as before."""
+        for the caller exactly as before.
+        eager_dense (dense_group + inputs_ready only; default off): the dense stages of a group are enqueued on the
+        caller's stream at once, right behind the group's sampling launch (they wait for its event on the device), instead
+        of at the step that hands out the group's first batch up to `group` steps later. Built in round 6 on the reading
+        that a short timed window leaves the device waiting for the host to reach a group boundary -- and measured WORSE:
+        the driver's 20-step window 40.7-40.9k pairs/s against 42.3-43.1k, 200 steps 46.5k against 47.2k (three
+        alternating runs on one box, profiles/NOTES.md). With the dense stages enqueued ahead, a fence drains them too: a
+        window then opens on an EMPTY pipeline and its first dense launch waits for a whole sampling chain, where the
+        default finds groups that are sampled already and only need their dense stages. Kept as an option for callers
+        that want a group's outputs as early as the device can produce them (lowest result latency). A caller-supplied
+        `out` is filled by a copy of the group's outputs."""
         if dense_group and (ahead != 'knn' or group < 2):
             raise ValueError("dense_group needs ahead='knn' and group > 1")
         if depth < 1:
@@ -62,6 +73,9 @@ class PipelinedForward:
         self._ahead = ahead
         self._dense_group = dense_group
         self._inputs_ready = inputs_ready
+        self._eager = bool(eager_dense)
+        if self._eager and not (dense_group and inputs_ready):
+            raise ValueError("eager_dense needs dense_group and inputs_ready")
         self._in_place = hasattr(model, '_cloud_layers') and os.environ.get('DCLR_BATCH_VIEW', '1') != '0'   # A/B: 0 = always concatenate
         self._planned = False                       # launch plans of the side streams built (first _launch)
         self._hold_launch = False                   # dense groups: a full sampling group is launched right AFTER the next
@@ -152,15 +166,34 @@ class PipelinedForward:
                     done.record(side)
                     for b in xs:
                         b.record_stream(side)
-                    self._pending.append((xs, (rows, prep), done))
-                    return
-                big = torch.cat(xs)
-                rows = self._model.cloud_feature_rows(big, self._model.sample(big))
-                outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
-            if self._ahead == 'knn' and not prepped:
-                outs = [(rows, self._model.merge_prep(rows, b.shape[0] // 2)) for b, rows in zip(xs, outs)]
-            done = torch.cuda.Event()
-            done.record(side)
+                    if not self._eager:
+                        self._pending.append((xs, (rows, prep), done))
+                        return
+                    eager = (rows, prep, done, half * len(xs))
+                if not self._dense_group:
+                    big = torch.cat(xs)
+                    rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+                    outs = list(rows.view(len(xs), -1, rows.shape[-1]).unbind(0))
+            if self._dense_group and len(xs) > 1:
+                pass                                             # (eager: the dense stages follow below, on the caller's stream)
+            else:
+                if self._ahead == 'knn' and not prepped:
+                    outs = [(rows, self._model.merge_prep(rows, b.shape[0] // 2)) for b, rows in zip(xs, outs)]
+                done = torch.cuda.Event()
+                done.record(side)
+        if self._dense_group and len(xs) > 1:
+            # eager_dense: flow embedding, head and fully connected tail of the whole group, enqueued now on the caller's
+            # stream behind the sampling launch's event; step() of the group's first batch finds the outputs
+            rows, prep, done, want = eager
+            main.wait_event(done)
+            for t in self._tensors((rows, prep)):
+                t.record_stream(main)
+            with torch.no_grad():
+                y_all = self._model.merge_rows(rows, want, prep=prep)
+            if hasattr(prep, 'release'):
+                prep.release()
+            self._pending.append((xs, y_all, None))
+            return
         for b, out in zip(xs, outs):
             b.record_stream(side)
             self._pending.append((b, out, done))
@@ -194,7 +227,7 @@ class PipelinedForward:
             batches, y_all = self._group_out
             pos = y_all.shape[0] // (x.shape[0] // 2) - len(batches)
             batches.pop(0)
-            self._hold_launch = True
+            self._hold_launch = not self._eager              # eager: a group that fills is launched (with its dense stages) at once
             for nxt in upcoming:
                 if self.in_flight() >= self.depth * self.group:
                     break
@@ -206,17 +239,23 @@ class PipelinedForward:
         if not self._pending and self._waiting and self._waiting[0] is x:
             self._launch()                                   # end of a stream of batches: the group never filled
         if self._pending and isinstance(self._pending[0][0], list) and self._pending[0][0][0] is x:
-            xs, (rows, prep), done = self._pending.popleft()
-            main.wait_event(done)
-            for t in self._tensors((rows, prep)):
-                t.record_stream(main)
+            xs, payload, done = self._pending.popleft()
             pairs = x.shape[0] // 2
             want = len(xs) * pairs
             whole = out is not None and out.shape[0] == want
-            with torch.no_grad():
-                y_all = self._model.merge_rows(rows, want, prep=prep, out=out if whole else None)
-            if hasattr(prep, 'release'):
-                prep.release()                               # its buffers may be reused once these launches are through
+            if done is None:                                 # eager_dense: enqueued behind the group's sampling launch already
+                y_all = payload
+                if whole:
+                    y_all = out.copy_(y_all)
+            else:
+                rows, prep = payload
+                main.wait_event(done)
+                for t in self._tensors((rows, prep)):
+                    t.record_stream(main)
+                with torch.no_grad():
+                    y_all = self._model.merge_rows(rows, want, prep=prep, out=out if whole else None)
+                if hasattr(prep, 'release'):
+                    prep.release()                           # its buffers may be reused once these launches are through
             self._group_out = (list(xs[1:]), y_all)
             # the dense stages are enqueued (one foreign call); now the sampling group held back during the slice steps
             # and whatever else fits the pipeline depth

@@ -602,10 +602,29 @@ def test_pipelined_runner_with_inputs_ready_and_buffer_ring_reuse():
     torch.cuda.synchronize()
     for depth, group, dense in ((1, 1, False), (2, 1, False), (1, 2, True), (2, 2, True), (3, 2, False)):
         runner = PipelinedForward(model, depth=depth, ahead='knn', group=group, dense_group=dense, inputs_ready=True)
+        assert not runner._eager                             # the default: a group's dense stages at its first step
         got = list(runner.run(batches))
         assert len(got) == len(want)
         for i, (a, b) in enumerate(zip(got, want)):
             assert torch.equal(a, b), (depth, group, dense, i)
+    # round 6: the dense stages of a group enqueued right behind its sampling launch (eager_dense, an option: measured
+    # slower in a short window) or at the group's first step (the default): the same outputs, also into a caller's buffer
+    with pytest.raises(ValueError):
+        PipelinedForward(model, depth=2, ahead='knn', group=2, dense_group=True, inputs_ready=False, eager_dense=True)
+    for eager in (True, False):
+        runner = PipelinedForward(model, depth=2, ahead='knn', group=3, dense_group=True, inputs_ready=True, eager_dense=eager)
+        assert runner._eager == eager
+        outs = torch.zeros(len(batches), 2, want[0].shape[1], device=DEV)
+        for i in range(min(len(batches), runner.depth * runner.group)):
+            runner.prefetch(batches[i], flush=False)
+        for i, b in enumerate(batches):
+            n_out = runner.group_start(b)
+            buf = outs[i:i + n_out].view(-1, outs.shape[-1]) if n_out else None
+            y = runner.step(b, upcoming=batches[i + 1:], out=buf)
+            assert torch.equal(y, want[i]), (eager, i)
+            if n_out:
+                torch.cuda.synchronize()
+                assert torch.equal(outs[i:i + n_out].view(-1, outs.shape[-1]), torch.cat(want[i:i + n_out])), (eager, i)
 
 
 @pytest.mark.parametrize('kind, pairs, n', [('kitti', 2, 2048), ('modelnet', 3, 2048), ('kitti', 1, 16384), ('kitti', 1, 20000)])
