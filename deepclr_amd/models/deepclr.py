@@ -798,20 +798,25 @@ class DeepCLR(BaseModel):
     def __init__(self, input_dim: int, label_type: LabelType, cloud_features: Config, merge: Config,
                  output: Config, transform: Optional[Config] = None, loss: Optional[Any] = None, **kwargs: Any):
         super().__init__()
-        if transform is not None:
-            raise NotImplementedError("no shipped model configures a transform layer")
         self._input_dim = input_dim
         cloud_features, merge, output = (Config.from_dict(c) if not isinstance(c, Config) else c
                                          for c in (cloud_features, merge, output))
-        cloud = _init_module(cloud_features, input_dim=input_dim, **kwargs)
+        # optional module in front of the per-cloud features (reference deepclr.py:453-454,460-464: `_cloud_layers` is then
+        # [transform, cloud features] and the state_dict keys shift by one). No shipped configuration names one and the
+        # only per-cloud module class the reference has is SetAbstraction: such a model runs module by module.
+        front = None
+        if transform is not None:
+            front = _init_module(transform if isinstance(transform, Config) else Config.from_dict(transform),
+                                 input_dim=input_dim, **kwargs)
+        cloud = _init_module(cloud_features, input_dim=input_dim if front is None else front.output_dim(), **kwargs)
         merge_layer = _init_module(merge, input_dim=cloud.output_dim(), **kwargs)
         head = _init_module(output, input_dim=merge_layer.output_dim(), label_type=label_type, **kwargs)
-        self._cloud_layers = nn.Sequential(cloud)
+        self._cloud_layers = nn.Sequential(cloud) if front is None else nn.Sequential(front, cloud)
         self._merge_layers = nn.Sequential(merge_layer, head)
         # The fused row pipeline (rows F -> rows E -> pose) covers every shipped configuration; a configuration with other
         # layer widths / k / feature counts runs module by module in the reference's channel layout, every module composed
         # from the level-1 HIP operators where its own shape is not the fused one.
-        self._rows_path = all(getattr(mod, 'rows_path', False) for mod in (cloud, merge_layer, head))
+        self._rows_path = front is None and all(getattr(mod, 'rows_path', False) for mod in (cloud, merge_layer, head))
         # batch norm / dropout (`batch_norm: true`, `dropout` < 1): identity-like in eval mode (folded / skipped), but in
         # training mode they need batch statistics / random masks, which only the differentiable torch path provides
         self._train_only = any(isinstance(m, (nn.Dropout, nn.modules.batchnorm._BatchNorm)) for m in self.modules())
@@ -836,7 +841,7 @@ class DeepCLR(BaseModel):
 
     @property
     def npoint(self) -> int:
-        return self._cloud_layers[0].npoint
+        return self._cloud_layers[-1].npoint
 
     def prepare(self) -> None:
         """Build every kernel-side (packed) weight buffer now, on the current stream. Optional: they are built on
@@ -1074,7 +1079,7 @@ class DeepCLR(BaseModel):
         if m is not None:
             self._augment(x, m)
         if not self._rows_path:                       # reference: x.transpose(1, 2) -> cloud layers (deepclr.py:516-520)
-            return self._cloud_layers[0](x.transpose(1, 2).contiguous())
+            return self._cloud_layers(x.transpose(1, 2).contiguous())
         rows = self.cloud_feature_rows(x.contiguous())
         return ops.rows_to_channels(rows, x.shape[0], self.npoint, self._cloud_layers[0].output_dim() - 3)
 
@@ -1097,7 +1102,9 @@ class DeepCLR(BaseModel):
             else:
                 if m is not None:
                     self._augment(x, m)
-                feat = self._cloud_layers[0].forward_train(x.transpose(1, 2).contiguous())
+                feat = x.transpose(1, 2).contiguous()
+                for layer in self._cloud_layers:
+                    feat = layer.forward_train(feat)
             y_pred = self._merge_layers[1].forward_train(self._merge_layers[0].forward_train(feat))
         elif not self._rows_path:
             # module by module in the reference's channel layout (deepclr.py:494-499), each module on the HIP operators
@@ -1118,7 +1125,7 @@ class DeepCLR(BaseModel):
         loss = self._loss_layer(y_pred, y)
         aux = None
         if debug:
-            nfeat = self._cloud_layers[0].output_dim() - 3
+            nfeat = self._cloud_layers[-1].output_dim() - 3
             aux = {'x_aug': x if is_feat else (feat if f_rows is None else
                                                ops.rows_to_channels(f_rows, x.shape[0], self.npoint, nfeat))}
         return y_pred, loss, aux

@@ -161,20 +161,25 @@ def state_dict_shapes(cfg: dict) -> 'OrderedDict[str, Tuple[int, ...]]':
         shapes[base + '.running_var'] = (width,)
         shapes[base + '.num_batches_tracked'] = ()
 
-    sa = prm['cloud_features']['params']
+    # per-cloud modules in `_cloud_layers` order: an optional `transform` module first (reference deepclr.py:453-464)
+    cloud_mods = ([prm['transform']] if prm.get('transform') else []) + [prm['cloud_features']]
     feat_in = cfg['input_dim'] - cfg['point_dim']
-    for lv in range(len(sa['mlps'])):            # level 1 specs start with their input width (deepclr.py:61 vs 73)
-        sa_out = 0
-        for s, spec in enumerate(sa['mlps'][lv]):
-            chans = [feat_in + 3, *spec] if lv == 0 else [spec[0] + 3, *spec[1:]]
-            for j in range(len(chans) - 1):
-                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}'.format(lv, s, j)
-                shapes[base + '.conv.weight'] = (chans[j + 1], chans[j], 1, 1)
-                if bn:
-                    norm(base + '.bn.bn', chans[j + 1])
-                else:
-                    shapes[base + '.conv.bias'] = (chans[j + 1],)
-            sa_out += spec[-1]
+    sa_out = 0
+    for mi, mod in enumerate(cloud_mods):
+        sa = mod['params']
+        for lv in range(len(sa['mlps'])):            # level 1 specs start with their input width (deepclr.py:61 vs 73)
+            sa_out = 0
+            for s, spec in enumerate(sa['mlps'][lv]):
+                chans = [feat_in + 3, *spec] if lv == 0 else [spec[0] + 3, *spec[1:]]
+                for j in range(len(chans) - 1):
+                    base = '_cloud_layers.{}._sa{}.mlps.{}.layer{}'.format(mi, lv, s, j)
+                    shapes[base + '.conv.weight'] = (chans[j + 1], chans[j], 1, 1)
+                    if bn:
+                        norm(base + '.bn.bn', chans[j + 1])
+                    else:
+                        shapes[base + '.conv.bias'] = (chans[j + 1],)
+                sa_out += spec[-1]
+        feat_in = sa_out                             # the next module's input features
 
     def stack(prefix: str, chans, conv: bool, step: int = 1) -> None:
         for j in range(len(chans) - 1):

@@ -126,14 +126,19 @@ class OracleDeepCLR:
         self.lin_step = 2 if float(prm.get('dropout', 1.0)) < 1.0 else 1     # helper.py:107-113: Dropout behind every Linear
         self.input_dim = int(model_cfg['input_dim'])
         self.point_dim = int(model_cfg['point_dim'])
-        sa = prm['cloud_features']['params']
-        assert prm['cloud_features']['name'] == 'SetAbstraction' and 1 <= len(sa['npoint']) <= 2
-        # one entry per set-abstraction level (deepclr.py:63-83): level 1's mlp specs START with their input width,
-        # level 0's do not (deepclr.py:61 vs 73)
-        self.sa_levels = [{'npoint': int(sa['npoint'][lv]), 'radii': [float(r) for r in sa['radii'][lv]],
-                           'nsamples': [int(s) for s in sa['nsamples'][lv]],
-                           'layers': [len(m) - (1 if lv == 1 else 0) for m in sa['mlps'][lv]]}
-                          for lv in range(len(sa['npoint']))]
+        # per-cloud modules in `_cloud_layers` order: an optional `transform` module, then the cloud features
+        # (deepclr.py:453-464); the reference's only per-cloud module class is SetAbstraction
+        mods = ([prm['transform']] if prm.get('transform') else []) + [prm['cloud_features']]
+        # one entry per (module, set-abstraction level) (deepclr.py:63-83): level 1's mlp specs START with their input
+        # width, level 0's do not (deepclr.py:61 vs 73)
+        self.sa_levels = []
+        for mi, mod in enumerate(mods):
+            sa = mod['params']
+            assert mod['name'] == 'SetAbstraction' and 1 <= len(sa['npoint']) <= 2
+            self.sa_levels += [{'module': mi, 'level': lv, 'npoint': int(sa['npoint'][lv]), 'radii': [float(r) for r in sa['radii'][lv]],
+                                'nsamples': [int(s) for s in sa['nsamples'][lv]],
+                                'layers': [len(m) - (1 if lv == 1 else 0) for m in sa['mlps'][lv]]}
+                               for lv in range(len(sa['npoint']))]
         self.npoint = self.sa_levels[-1]['npoint']
         me = prm['merge']['params']
         assert prm['merge']['name'] == 'MotionEmbedding'
@@ -150,9 +155,9 @@ class OracleDeepCLR:
         x = x.to(torch.float32).transpose(1, 2)                        # (2B, C, N)
         xyz = x[:, :3, :].transpose(1, 2).contiguous()
         feats = x[:, 3:, :].contiguous() if x.size(1) > 3 else None
-        for lv, level in enumerate(self.sa_levels):                    # deepclr.py:90-93
+        for level in self.sa_levels:                                   # deepclr.py:90-93, module after module (516-520)
             def layer(s, j):
-                base = '_cloud_layers.0._sa{}.mlps.{}.layer{}'.format(lv, s, j)
+                base = '_cloud_layers.{}._sa{}.mlps.{}.layer{}'.format(level['module'], level['level'], s, j)
                 return self.sd[base + '.conv.weight'], self.sd.get(base + '.conv.bias'), _norm_of(self.sd, base + '.bn.bn')
             weights = [[layer(s, j) for j in range(n)] for s, n in enumerate(level['layers'])]
             xyz, feats = sa_msg_forward(xyz, feats, level['npoint'], level['radii'], level['nsamples'], weights)

@@ -103,7 +103,8 @@ def _ref_model(ref, cfg: dict, sd):
     prm = cfg['params']
     model = ref.DeepCLR(input_dim=cfg['input_dim'], label_type=LabelType.create(cfg['label_type']),
                         cloud_features=sub(prm['cloud_features']), merge=sub(prm['merge']),
-                        output=sub(prm['output']), point_dim=cfg['point_dim'],
+                        output=sub(prm['output']), transform=sub(prm['transform']) if prm.get('transform') else None,
+                        point_dim=cfg['point_dim'],
                         batch_norm=prm['batch_norm'], dropout=prm['dropout'])
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -191,6 +192,8 @@ CASES = [
     ('small_bn_n512_b2', helpers.small_bn_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=23), 19, True),
     # more neighbours than the search's rank selection (and the fused flow kernel) take: k = 70 of 128 source centroids
     ('small_k70_n512_b2', helpers.small_k70_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=29), 20, True),
+    # a `transform` module (a SetAbstraction of its own) in front of the cloud features (deepclr.py:447,453-464)
+    ('small_transform_n512_b2', helpers.small_transform_cfg, lambda: synthetic.make_batch('kitti', 2, 512, first_pair=31), 21, True),
 ]
 
 
@@ -219,20 +222,25 @@ def run_case(ref, name, cfg, x_np, wseed, full):
     mats_or = np.stack([olabels.dual_quat_to_matrix(v.numpy()) for v in y_or])
     assert np.abs(mats_ref - mats_or).max() < 1e-6, name
 
-    # primitive-level records from the oracle (what the reference composition consumed)
-    sa = cfg['params']['cloud_features']['params']
+    # primitive-level records from the oracle (what the reference composition consumed); the sampling levels in order: those
+    # of an optional `transform` module, then those of the cloud features
+    prm = cfg['params']
+    levels = [(m['params']['npoint'][lv], m['params']['radii'][lv], m['params']['nsamples'][lv])
+              for m in ([prm['transform']] if prm.get('transform') else []) + [prm['cloud_features']]
+              for lv in range(len(m['params']['npoint']))]
+    assert 1 <= len(levels) <= 2
     xyz = x[:, :, :3].contiguous()
-    fps_idx = oracle.furthest_point_sample(xyz, sa['npoint'][0])
+    fps_idx = oracle.furthest_point_sample(xyz, levels[0][0])
     new_xyz = oracle.gather_operation(xyz.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
     extra = {}
-    if len(sa['npoint']) == 1:
+    if len(levels) == 1:
         assert torch.equal(new_xyz.transpose(1, 2), feat_ref[:, :3, :])
-    else:                                        # second level samples the level-0 centroids (deepclr.py:92-93)
-        fps_idx1 = oracle.furthest_point_sample(new_xyz, sa['npoint'][1])
+    else:                                        # the second level samples the first one's centroids (deepclr.py:92-93, 516-520)
+        fps_idx1 = oracle.furthest_point_sample(new_xyz, levels[1][0])
         new_xyz1 = oracle.gather_operation(new_xyz.transpose(1, 2).contiguous(), fps_idx1)
         assert torch.equal(new_xyz1, feat_ref[:, :3, :])
         extra['fps_idx1'] = fps_idx1.numpy().astype(np.int16)
-    bq = [oracle.ball_query(r, s, xyz, new_xyz) for r, s in zip(sa['radii'][0], sa['nsamples'][0])]
+    bq = [oracle.ball_query(r, s, xyz, new_xyz) for r, s in zip(levels[0][1], levels[0][2])]
     half = feat_ref.shape[0] // 2
     npoint = feat_ref.shape[2]
     if cfg['params']['merge']['params']['k'] > 0:

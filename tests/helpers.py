@@ -26,6 +26,9 @@ GOLDEN_CASES = {
     'small_bn_n512_b2': ('small_bn', True),
     # k = 70 neighbours of 128 source centroids (reference deepclr.py:180-199 takes any k; the search's rank selection stops at 40)
     'small_k70_n512_b2': ('small_k70', True),
+    # a `transform` module in front of the cloud features (reference deepclr.py:447,453-464; no shipped config has one):
+    # 512 points -> 128 centroids x 64 features (module 0) -> 64 centroids x (32 + 32) features (module 1)
+    'small_transform_n512_b2': ('small_transform', True),
 }
 
 
@@ -41,6 +44,18 @@ def small_cfg() -> dict:
 def small_global_cfg() -> dict:
     cfg = small_cfg()
     cfg['params']['merge']['params'].update(k=0, radius=6.0)
+    return cfg
+
+
+def small_transform_cfg() -> dict:
+    """`transform`: a SetAbstraction of its own in front of the cloud features (`_cloud_layers` = [transform, features]; the
+    reference's only per-cloud module class). The feature module's level 0 then takes 64 input features."""
+    cfg = small_cfg()
+    cfg['params']['transform'] = {'name': 'SetAbstraction', 'params': {
+        'npoint': [128], 'radii': [[2.0, 4.0]], 'nsamples': [[8, 16]], 'mlps': [[[16, 16, 32], [16, 16, 32]]]}}
+    sa = cfg['params']['cloud_features']['params']
+    sa['npoint'], sa['radii'], sa['nsamples'] = [64], [[4.0, 8.0]], [[8, 24]]
+    sa['mlps'] = [[[32, 32], [48, 32]]]
     return cfg
 
 
@@ -110,6 +125,8 @@ def case_cfg(name: str) -> dict:
         return small_k70_cfg()
     if kind == 'small_two_level':
         return small_two_level_cfg()
+    if kind == 'small_transform':
+        return small_transform_cfg()
     return small_cfg() if kind == 'small' else synthetic.model_cfg(kind)
 
 

@@ -17,7 +17,8 @@ def test_oracle_reproduces_golden(name):
     g, cfg, sd = load_golden(name)
     orc = oracle.build_oracle_model(cfg, sd)
     x = torch.from_numpy(g['x'])
-    sa = cfg['params']['cloud_features']['params']
+    prm = cfg['params']
+    sa = (prm.get('transform') or prm['cloud_features'])['params']    # the module that samples the raw clouds
     xyz = x[:, :, :3].contiguous()
 
     fps = oracle.furthest_point_sample(xyz, sa['npoint'][0])
