@@ -17,7 +17,7 @@ static inline int dclr_launch_status() {
     return e == hipSuccess ? DCLR_OK : -(1000 + (int)e);
 }
 
-// ---- library-internal forms of two level-2 entry points (not exported): the split-f16 kernels with the word that
+// ---- library-internal forms of three level-2 entry points (not exported): the split-f16 kernels with the word that
 // receives 1 when an activation left the f16 range (overflow, NULL = not reported), and -- flow embedding -- a buffer of
 // zero_count floats the kernel clears on its way (the head's column maxima: saves the fill launch between the two).
 #define DCLR_INTERNAL __attribute__((visibility("hidden")))
@@ -30,6 +30,10 @@ DCLR_INTERNAL int dclr_x_flow_embedding_fused_f16(int pairs, int npoint, int k, 
                                                   const float *w1a, const float *b1, const void *w2p, const float *b2,
                                                   const void *w3p, const float *b3, float *e_rows, float *zero,
                                                   long long zero_count, uint32_t *overflow, dclr_stream_t stream);
+
+// dclr_fc with the overflow word as `poison`: set -> the outputs are written as NaN (the last layer of dclr_merge_forward)
+DCLR_INTERNAL int dclr_x_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act, float *y,
+                            const uint32_t *poison, dclr_stream_t stream);
 
 // ---- frozen distance recipe (include/deepclr_amd.h): (dx*dx + dy*dy) + dz*dz, no contraction.
 // The whole library is built with -ffp-contract=off; MLP code asks for FMA explicitly (fmaf).

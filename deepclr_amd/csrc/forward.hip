@@ -64,7 +64,10 @@ extern "C" int dclr_merge_forward(const DclrMergeArgs *a, void *const *events, d
     const float *x = a->colmax;
     for (int l = 0; l < a->n_fc; ++l) {
         float *out = l == a->n_fc - 1 ? a->y : a->fc_tmp[l & 1];
-        rc = dclr_fc(a->pairs, a->fc_n[l], a->fc_k[l], x, a->fc_w[l], a->fc_b[l], a->fc_act[l], out, stream);
+        // the last layer writes NaN poses when the sticky overflow word is set (a clamped activation in this or an earlier
+        // forward the host has not acknowledged yet): never a plausible-looking wrong pose
+        const uint32_t *poison = (l == a->n_fc - 1 && a->precision == 1) ? a->overflow : nullptr;
+        rc = dclr_x_fc(a->pairs, a->fc_n[l], a->fc_k[l], x, a->fc_w[l], a->fc_b[l], a->fc_act[l], out, poison, stream);
         if (rc != DCLR_OK) return rc;
         mark();
         x = out;

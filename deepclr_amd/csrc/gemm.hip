@@ -248,9 +248,14 @@ __device__ __forceinline__ float fc_wave_sum(float v) {
 __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, const float *__restrict__ x,
                                                            const float *__restrict__ w,
                                                            const float *__restrict__ bias, int act,
-                                                           float *__restrict__ y) {
+                                                           float *__restrict__ y, const uint32_t *poison) {
     __shared__ float xs[FC_ROWS][FC_MAX_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // poison (the LAST layer of the fused dense stages on the split-f16 path): the sticky word the kernels before this one
+    // set when an activation was clamped at the f16 range. Set -> the outputs are written as NaN: a clamped forward hands
+    // out poses that cannot be mistaken for results, whether or not the host looks at the word again (it does, at its
+    // next entry into the model). One scalar load, requested first, needed last.
+    const bool bad = poison != nullptr && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
     const int col = blockIdx.x * FC_WAVES + wave;
     const bool live = col < n;                                       // wave-uniform
     float wv[FC_CHUNKS];
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(int m, int n, int k, 
             if (act == 1) v = fmaxf(v, 0.f);
             else if (act == 2) v = col == 0 ? 1.f / (1.f + expf(-v)) : (col < 4 ? tanhf(v) : v);
             else if (act == 3) v = col == 3 ? 1.f / (1.f + expf(-v)) : (col > 3 ? tanhf(v) : v);
+            if (bad) v = __builtin_nanf("");
             if ((lane & 7) == 0 && r < rows) y[(size_t)(r0 + r) * n + col] = v;
         }
     }
@@ -406,10 +412,15 @@ extern "C" int dclr_head_conv_fused(int m, int n_layers, const int *k_host, cons
 
 extern "C" int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act,
                        float *y, dclr_stream_t stream) {
+    return dclr_x_fc(m, n, k, x, w, bias, act, y, nullptr, stream);
+}
+
+int dclr_x_fc(int m, int n, int k, const float *x, const float *w, const float *bias, int act, float *y,
+              const uint32_t *poison, dclr_stream_t stream) {
     DCLR_REQUIRE(m > 0 && n > 0 && k > 0 && x && w && y && act >= 0 && act <= 3);
     if (k > FC_MAX_K) return DCLR_E_UNSUPPORTED;
     const int row_blocks = (m + FC_ROWS - 1) / FC_ROWS;
     hipLaunchKernelGGL(fc_kernel, dim3((n + FC_WAVES - 1) / FC_WAVES, row_blocks < 64 ? row_blocks : 64), dim3(FC_WAVES * 64), 0,
-                       (hipStream_t)stream, m, n, k, x, w, bias, act, y);
+                       (hipStream_t)stream, m, n, k, x, w, bias, act, y, poison);
     return dclr_launch_status();
 }

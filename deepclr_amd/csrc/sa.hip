@@ -197,7 +197,9 @@ __device__ __noinline__ void sa_drain(const float *cloud, int wave, int s, int h
             x2 = __builtin_amdgcn_mfma_f32_16x16x16f16(a2l, b1h, x2, 0, 0, 0);
             dclr_split2_relu(fmaf(x2[0], DCLR_SPLIT_INV, h2[0]), fmaf(x2[1], DCLR_SPLIT_INV, h2[1]), p0, q0, peak);
             dclr_split2_relu(fmaf(x2[2], DCLR_SPLIT_INV, h2[2]), fmaf(x2[3], DCLR_SPLIT_INV, h2[3]), p1, q1, peak);
+#ifndef DCLR_SA_NO_OVF
             clamped |= __ballot(peak > DCLR_F16_MAX);
+#endif
             const dclr_h4 b2h = {p0[0], p0[1], p1[0], p1[1]}, b2l = {q0[0], q0[1], q1[0], q1[1]};
 #pragma unroll
             for (int u = 0; u < 2; ++u) {

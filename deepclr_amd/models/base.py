@@ -59,14 +59,17 @@ class ModelInferenceHelper:
         self._state = None
 
     def finish(self) -> None:
-        """Wait for the model's work in flight and raise if any of it left the range of the split-f16 matrix path (its
-        poses are wrong: deepclr_amd.models.DeepCLR.check_range). Every predict* method ends with it, so that the result
-        it hands out -- the last or only one of a run included -- is never a silently clamped one; the reference's
-        scripts read each result on the host right away (scripts/inference.py:104-107, timing.py:41-44), which waits for
-        the same work. Models without such a check (the reference interface has none): a no-op."""
+        """Wait for the model's work on the current stream and raise if any of it left the range of the split-f16 matrix
+        path (deepclr_amd.models.DeepCLR.check_range). A clamped forward is never silent even without this call: the fused
+        kernels write its poses as NaN (and every later one's, until the host has acknowledged the flag), and the next
+        entry into the model raises. `predict_batch` and `predict_sequence` end with finish() (one wait per batch);
+        `predict` -- one pair per call, timed per call by the reference's scripts (scripts/timing.py:36-44) -- does not:
+        a host-side wait behind every pair costs ~20 us of its 0.82 ms, so a caller of `predict` gets NaN poses from a
+        clamped pair, the exception at the next call, or the exception here when it calls finish() after its last pair.
+        Models without such a check (the reference interface has none): a no-op."""
         check = getattr(self._model, 'check_range', None)
         if check is not None:
-            check(synchronize=True)
+            check(synchronize='stream')
 
     def _fit_columns(self, cloud: torch.Tensor, which: str) -> torch.Tensor:
         cols = cloud.shape[1]
@@ -94,13 +97,11 @@ class ModelInferenceHelper:
                 if previous is None:
                     return None
                 y, _, _ = self._model.forward(self.stack(previous, feat), is_feat=True)
-                self.finish()
                 return y[0, :]
 
             if template is None:
                 raise RuntimeError("Source and template clouds are required for non-sequential prediction.")
             y, _, _ = self._model.forward(self.stack(template, source), is_feat=False)
-            self.finish()
             return y[0, :]
 
     def predict_batch(self, sources: torch.Tensor, templates: torch.Tensor) -> torch.Tensor:

@@ -13,6 +13,7 @@ Out of scope here: losses (a ground truth ``y`` raises), b
 import abc
 import ctypes
 import os
+import time
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -905,7 +906,7 @@ class DeepCLR(BaseModel):
         return plan.run(x, stride, events, merge_events)
 
     def _cloud_plan(self, sa0, x: torch.Tensor, per: int, nb: int):
-        key = ('cloud', x.device, per, nb, x.shape[1], ops.PRECISION, lib.stream_ptr())
+        key = ('cloud', x.device, per, nb, x.shape[1], ops.PRECISION, ops.CHECK_RANGE == 'never', lib.stream_ptr())
         plan = self._plan_lookup(key)
         if plan is None or not plan.current():
             merge_plan = self._merge_plan(x, per * nb)
@@ -977,18 +978,21 @@ class DeepCLR(BaseModel):
                                "(ModelInferenceHelper does); a training step runs with gradients enabled")
 
     def _range_flag_ptr(self) -> Optional[int]:
-        if ops.PRECISION != 'f16x2':
+        """Device address of the word the split-f16 kernels report a clamped activation to -- and read back: while it is set,
+        the fused dense stages write their poses as NaN (csrc/gemm.hip fc_kernel). None on the f32 matrix path and with
+        CHECK_RANGE = 'never' (the caller opted out: nothing is tracked, nothing poisoned)."""
+        if ops.PRECISION != 'f16x2' or ops.CHECK_RANGE == 'never':
             return None
         if self._range_flag is None:
             self._range_flag = lib.MappedFlag()
         return self._range_flag.dev_ptr
 
-    def check_range(self, synchronize: bool = False) -> None:
+    def check_range(self, synchronize=False) -> None:
         """Raise if a split-f16 forward that has COMPLETED since the last check clamped an activation at 65504 (its poses
         are wrong). The fused kernels set one word of mapped host memory when a clamp engages (csrc/mma16f.h
         dclr_report_overflow); reading it costs no device synchronisation, so every entry into the model looks at it --
         forward(), merge_rows(), the pipelined runner's steps -- and a caller that wants the verdict for work still in
-        flight passes synchronize=True. CHECK_RANGE='first' covers the first forward of a checkpoint (f32 re-run with
+        flight passes synchronize=True (the whole device) or 'stream' (the current stream). CHECK_RANGE='first' covers the first forward of a checkpoint (f32 re-run with
         a message that names the peak); this flag covers every later input."""
         flag = self._range_flag
         if flag is None:
@@ -996,7 +1000,18 @@ class DeepCLR(BaseModel):
         if ops.CHECK_RANGE == 'never':              # the caller opted out of range checks: nothing is reported, nothing kept
             flag.clear()
             return
-        if synchronize:
+        if synchronize == 'stream':
+            # the CURRENT stream only (ModelInferenceHelper.finish: a predict call's work is all there), polled for up to
+            # ~2 ms before blocking: a blocking wait returns ~20 us after the work is done, which a caller that times single
+            # pairs (scripts/timing.py) would see in every call
+            ev = torch.cuda.Event()
+            ev.record()
+            t_end = time.perf_counter() + 2e-3
+            while not ev.query():
+                if time.perf_counter() > t_end:
+                    ev.synchronize()
+                    break
+        elif synchronize:
             torch.cuda.synchronize()
         if flag.is_set():
             flag.clear()
@@ -1043,7 +1058,7 @@ class DeepCLR(BaseModel):
                 or not isinstance(head, OutputSimple) or not self._rows_path:
             return None
         # the workspace belongs to one stream: calls enqueued on different streams may run side by side
-        key = (f_rows.device, pairs, self.npoint, ops.PRECISION, lib.stream_ptr())
+        key = (f_rows.device, pairs, self.npoint, ops.PRECISION, ops.CHECK_RANGE == 'never', lib.stream_ptr())
         plan = self._plan_lookup(key)
         if plan is None or not plan.current():
             plan = _MergePlan.build(flow._embedding, head, f_rows.device, pairs, self.npoint, self._range_flag_ptr())

@@ -334,7 +334,9 @@ typedef struct DclrMergeArgs {
     float *y;                               /* out (pairs, fc_n[last]) */
     uint32_t *overflow;                     /* NULL, or one word (device memory, or host memory mapped into the device's
                                              * address space) that the split-fp16 kernels set to 1 when an activation
-                                             * exceeds 65504 and is clamped (precision == 1); sticky: the caller clears it */
+                                             * exceeds 65504 and is clamped (precision == 1); sticky: the caller clears it.
+                                             * While it is set the last fully connected layer writes y as NaN (ABI 0.2): a
+                                             * clamped forward never hands out plausible-looking poses */
 } DclrMergeArgs;
 int dclr_merge_forward(const DclrMergeArgs *args, void *const *events, dclr_stream_t stream);
 

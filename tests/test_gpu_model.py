@@ -872,9 +872,11 @@ def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_orac
 
 def test_inference_helper_reports_a_clamped_last_forward():
     """the sticky range flag used to be read only on the NEXT entry into the model, so the last (or only)
-    forward of a run could hand out clamped poses silently. Every predict* method of the helper now ends with
-    finish() = check_range(synchronize=True); and the split-f16 set-abstraction layers report their clamps to the same
-    word (they used to clamp silently: only flow embedding and head were tracked)."""
+    forward of a run could hand out clamped poses silently. Now (1) the fused dense stages write NaN poses while the flag is
+    set -- a clamped forward cannot be mistaken for a result by ANY caller; (2) predict_batch / predict_sequence end with
+    finish() = check_range on the current stream and raise; (3) predict (one pair per call, the reference scripts' timed
+    pattern) returns the NaN pose, raises at the next call, or at finish(); and the split-f16 set-abstraction layers report
+    their clamps to the same word (they used to clamp silently: only flow embedding and head were tracked)."""
     cfg = synthetic.model_cfg('kitti')
     sd = synthetic.random_state_dict(cfg, seed=4)
     model, _ = _models(cfg, sd)
@@ -887,9 +889,19 @@ def test_inference_helper_reports_a_clamped_last_forward():
     with pytest.raises(RuntimeError, match='DCLR_PRECISION=f32'):
         helper.predict_batch(hot[2:], hot[:2])                           # ONE call, nothing after it: raises, no pose handed out
     _close(helper.predict_batch(x[2:], x[:2]), y_ok.cpu(), stage='in-range batch after the reported one')
+    y_hot = helper.predict(hot[2], hot[0])                               # the reference scripts' call pattern: no wait inside
+    assert bool(torch.isnan(y_hot.cpu()).all())                          # ... the clamped pair's pose is NaN, not a plausible vector
     with pytest.raises(RuntimeError, match='DCLR_PRECISION=f32'):
-        helper.predict(hot[2], hot[0])                                   # the reference scripts' call pattern
-    assert helper.predict(x[2], x[0]) is not None
+        helper.finish()                                                  # the caller's last word; (a next predict would raise too)
+    y_one = helper.predict(x[2], x[0])
+    assert y_one is not None and bool(torch.isfinite(y_one.cpu()).all())
+    helper.finish()
+    with torch.no_grad():                                                # plain forward(), no helper: NaN as well, raise at the next entry
+        y_fwd, _, _ = model(hot.clone())
+        assert bool(torch.isnan(y_fwd.cpu()).all())
+        with pytest.raises(RuntimeError, match='DCLR_PRECISION=f32'):
+            model(x.clone())
+        _close(model(x.clone())[0], y_ok.cpu(), stage='forward after the reported one')
     # the set-abstraction kernel by itself sets the word it is given
     flag = lib.MappedFlag()
     sam = model._cloud_layers[0]._sa0
@@ -970,10 +982,10 @@ def test_split_f16_range_guard(monkeypatch):
             model_big(x_cpu.to(DEV))
         monkeypatch.setattr(ops, 'CHECK_RANGE', 'never')
         y16, _, _ = model_big(x_cpu.to(DEV))                                               # unchecked: silently clamped ...
-        assert float((y16.cpu() - y_o).abs().max()) > 1e-3                                 # ... and therefore wrong
-        assert model_big._range_flag.is_set()                                              # (the kernels did notice)
-        model_big.check_range()                                                            # 'never': dropped, not reported
-        assert not model_big._range_flag.is_set()
+        assert float((y16.cpu() - y_o).abs().max()) > 1e-3                                 # ... and therefore wrong (finite: not poisoned)
+        assert bool(torch.isfinite(y16.cpu()).all())
+        assert model_big._range_flag is None or not model_big._range_flag.is_set()         # 'never': the kernels get no word at all
+        model_big.check_range()                                                            # nothing to report
         monkeypatch.setattr(ops, 'CHECK_RANGE', 'first')
         monkeypatch.setattr(ops, 'PRECISION', 'f32')
         y32, _, _ = model_big(x_cpu.to(DEV))

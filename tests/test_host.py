@@ -45,6 +45,15 @@ def test_state_dict_layout_matches_reference():
         assert out_bias.tolist() == [1.0, 0, 0, 0, 0, 0, 0, 0]           # LabelType.bias for dual quaternions
         assert float(sd['_merge_layers.1.conv._sequential.0._sequential.0.bias'].abs().max()) == 0.0
     assert model.get_input_dim() == 3 and not model.has_loss() and model.get_loss_weights() == {}
+    # a `transform` module (reference deepclr.py:447,453-464): `_cloud_layers` = [transform, cloud features], keys shifted by
+    # one, the feature module fed with the transform's 3 + 64 channels; such a model runs module by module
+    from helpers import small_transform_cfg
+    tr = build_model(model_config_from_dict(small_transform_cfg()))
+    shapes = synthetic.state_dict_shapes(small_transform_cfg())
+    assert {k: tuple(v.shape) for k, v in tr.state_dict().items()} == dict(shapes)
+    assert shapes['_cloud_layers.0._sa0.mlps.0.layer0.conv.weight'] == (16, 4, 1, 1)
+    assert shapes['_cloud_layers.1._sa0.mlps.1.layer0.conv.weight'] == (48, 67, 1, 1)
+    assert len(tr._cloud_layers) == 2 and not tr._rows_path and tr.npoint == 64
 
 
 def test_load_model_config_and_trained_model(tmp_path):
