@@ -978,7 +978,14 @@ def run(args):
     ops.TIMER = None
     if not stub:
         model.check_range()                      # the split-f16 kernels' sticky flag: a clamped activation = wrong poses = no line
-    recent_kept = list(recent)                   # the last two launch groups of the TIMED loop (pose check below)
+    # the last two launch groups of the TIMED loop (pose check below). Copies: with an all-gather the outputs are views of its
+    # send buffer, which the untimed passes below (latency_pass steps through the same closure when one rank runs with
+    # --force-dist) would overwrite -- BENCH collections of round 6 read a pose delta of 0.41 on `dist1` for that reason alone
+    recent_kept = [(b, yy.clone()) for b, yy in recent]
+    own_block_ok = None
+    if gather is not None and not stub:
+        # this rank's block of the last all-gather (flushed by the closing fence) is what it sent: RCCL moved the bytes
+        own_block_ok = bool(torch.equal(gather.gathered.view(world, -1)[rank], gather.send.view(-1)))
     alone, fps_rounds, latency = None, None, None
     if rank == 0 and not stub and world == 1:
         latency = latency_pass((args.depth + 4) * args.group if args.group > 1 else 5 * args.depth + 10)   # > the batches in flight
@@ -1113,6 +1120,8 @@ def run(args):
                              'batches_per_copy': feeder.chunk}
         if gather_check is not None:
             result['gather_check'] = gather_check
+        elif own_block_ok is not None:
+            result['gather_check'] = {'own_block_of_the_last_all_gather_equals_what_was_sent': own_block_ok, 'rank': 0}
         if roofline_sampler is not None:
             result['roofline_sampler'] = roofline_sampler
         if rooflines is not None:
