@@ -488,7 +488,8 @@ __global__ __launch_bounds__(256, T <= 6 ? 3 : 2) void flow32_kernel(int pairs, 
                 *reinterpret_cast<uint32_t *>(slot + s * F16_STRIDE + 16) = 0u;
             }
         }
-        if constexpr (ROWS > F16_G * KP) {                                // the 16 rows no point owns: zeros (finite sums)
+        if constexpr (ROWS > F16_G * KP) {                                // the 16 rows no point owns: zeros (finite sums; their
+                                                                          // layer-2 rows are relu(b2), their layer-3 rows ignored)
             static_assert(ROWS - F16_G * KP == 16, "tail rows");
             char *dst = tile + (F16_G * KP + (tid >> 4)) * F16_STRIDE + 32 * (tid & 15);
             *reinterpret_cast<float4 *>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -526,7 +527,6 @@ __global__ __launch_bounds__(256, T <= 6 ? 3 : 2) void flow32_kernel(int pairs, 
         for (int t = 0; t < RT; ++t) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                if (32 * t + 8 * g4 >= F16_G * KP) continue;              // rows no point owns stay zero
                 dclr_h4 hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {

@@ -834,6 +834,63 @@ def test_flow_embedding_split_fp16_against_f32_path_and_float64(k, radius):
     assert err16 <= 2 * err32 + 1e-7, (err16, err32)
 
 
+@pytest.mark.parametrize('pairs, npoint', [(3, 37), (8, 16), (1, 5)])
+def test_flow_kernels_at_every_neighbour_count_with_masks_and_unfilled_slots(pairs, npoint):
+    """Both split-f16 flow kernels (flow16_kernel up to k = 24, flow32_kernel from k = 25: csrc/flow16.hip) at EVERY k from 1 to
+    32 on hand-made neighbour lists: slots the search left unfilled (-1), neighbours beyond the radius (reference
+    deepclr.py:220-225: their columns are zeroed before the max), points with NO neighbour inside the radius (all zeros),
+    point counts that are not a multiple of the 4 points per workgroup, pair counts with and without the one-pair-one-XCD
+    block mapping -- against a float64 restatement, and the f32 kernel on the same lists."""
+    cfg = synthetic.model_cfg('kitti')
+    model, _ = _models(cfg, synthetic.random_state_dict(cfg, seed=13))
+    me = model._merge_layers[0]._embedding
+    p = me._packed()
+    (w1, b1), (w2, b2), (w3, b3) = me._conv.affine_params()
+    w64 = [(w.detach().double().reshape(w.shape[0], -1), b.detach().double()) for w, b in ((w1, b1), (w2, b2), (w3, b3))]
+    rng = np.random.default_rng(100 * pairs + npoint)
+    rows = 2 * pairs * npoint
+    f = np.zeros((rows, ops.F_STRIDE), dtype=np.float32)
+    f[:, :64] = np.abs(rng.normal(size=(rows, 64)))
+    f[:, 64:67] = rng.normal(scale=1.5, size=(rows, 3))
+    f_rows = torch.from_numpy(f).to(DEV)
+    half = pairs * npoint
+    # per-point halves of layer 1 (dclr_linear_pair wants whole 32-row tiles; any row count through torch, in float64)
+    w1f = w1.detach().double().reshape(w1.shape[0], -1)
+    pt = (f_rows[:half, :64].double() @ w1f[:, 3:67].t()).float().contiguous()
+    ps = (f_rows[half:, :64].double() @ w1f[:, 67:131].t()).float().contiguous()
+    radius = 2.0
+    f64 = f_rows.double()
+    tmpl, src = f64[:half].view(pairs, npoint, -1), f64[half:].view(pairs, npoint, -1)
+    tiles = set()
+    for k in range(1, 33):
+        idx = rng.integers(0, npoint, size=(pairs, npoint, k)).astype(np.int32)
+        idx[rng.random(idx.shape) < 0.15] = -1                              # unfilled slots anywhere in the list
+        idx[0, 0, :] = -1                                                   # a point without any neighbour
+        far = np.linalg.norm(f[half:].reshape(pairs, npoint, -1)[:, :, 64:67][np.arange(pairs)[:, None], idx[:, 1].clip(0)]
+                             - f[:half].reshape(pairs, npoint, -1)[:, 1:2, 64:67], axis=-1) >= radius
+        idx[:, 1][~far & (idx[:, 1] >= 0)] = -1                             # point 1: only neighbours beyond the radius (or none)
+        idx_t = torch.from_numpy(idx).to(DEV)
+        tile = ops.flow_f16_tile(k)
+        tiles.add(tile)
+        w2h, w3h = ops.pack_weight_f16(w2, 128, tile), ops.pack_weight_f16(w3, 128, tile)
+        e16 = ops.flow_embedding_fused_f16(f_rows, idx_t, pt, ps, p['w1a'], p['b1'], w2h, p['b2'], w3h, p['b3'], radius)
+        e32 = ops.flow_embedding_fused(f_rows, idx_t, pt, ps, p['w1a'], p['b1'], p['w2p'], p['b2'], p['w3p'], p['b3'], radius)
+        li = torch.from_numpy(idx.clip(0)).long().to(DEV)
+        nb = torch.gather(src.unsqueeze(1).expand(-1, npoint, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, f64.shape[1]))
+        diff = nb[..., 64:67] - tmpl[:, :, None, 64:67]
+        h = torch.cat((diff, tmpl[:, :, None, :64].expand(-1, -1, k, -1), nb[..., :64]), dim=-1)
+        for w, b in w64:
+            h = torch.relu(h @ w.t() + b)
+        dead = (diff.norm(dim=-1, keepdim=True) >= radius) | (idx_t < 0).unsqueeze(-1)
+        want = torch.where(dead, torch.zeros_like(h), h).max(dim=2).values.view(half, 256)
+        assert bool((want[0] == 0).all()) and bool((want[npoint * 0 + 1] == 0).all())      # the two hand-made empty points
+        _close(e16[:, :256], want.float().cpu(), stage='flow kernel k=%d (tile %d) vs float64' % (k, tile))
+        _close(e32[:, :256], want.float().cpu(), stage='f32 flow kernel k=%d vs float64' % k)
+        assert torch.equal(e16[:, 256:259], f_rows[:half, 64:67]) and bool((e16[:, 259:] == 0).all())
+        assert torch.equal(e16 == 0, e32 == 0)                              # the same columns are empty on both paths
+    assert tiles <= {16, 32} and 32 in tiles                             # (an A/B build may force one tile for every k)
+
+
 def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_oracle():
     """`forward(x, m=m)` / `cloud_features(x, m)`: the homogeneous transforms m (2B, 4, 4) are applied to the point
     columns of x IN PLACE before set abstraction (reference: deepclr.py:512-514, tgm.transform_points(m, x[:, :, :3]));

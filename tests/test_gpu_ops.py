@@ -78,6 +78,23 @@ def test_fps_reproduces_the_reference_numpy_sampler(golden_dir):
             assert np.array_equal(row, g[n + '/picks']), n
 
 
+@pytest.mark.parametrize('kind, b, n, m', [('normal', 2, 20000, 200), ('kitti', 1, 40000, 150), ('grid', 1, 65536, 64),
+                                           ('dup', 2, 17000, 300), ('line', 1, 32768, 100)])
+def test_fps_fallback_kernels_without_a_workspace(kind, b, n, m):
+    """dclr_fps_clouds on 16385..65536 points: no workspace in the signature, so the running minima stay in registers and the
+    coordinates are re-read every round (fps_stream_kernel<32> / <64>; also what dclr_furthest_point_sampling falls back to
+    when the stream-ordered allocator refuses). Round 6 rewrote their prologue and load scheduling (they spilled 252 / 904
+    bytes): same samples as the oracle, bit for bit, ties and duplicates included; with `temp`, the level-1 side effect too."""
+    from deepclr_amd import lib
+    xyz = _cloud(kind, b, n, 23)
+    want = oracle.furthest_point_sample(xyz, m)
+    x = xyz.to(DEV).contiguous()
+    idx = torch.full((b, m), -7, dtype=torch.int32, device=DEV)
+    lib.check(lib.load().dclr_fps_clouds(b, n, 3, m, x.data_ptr(), idx.data_ptr(), lib.stream_ptr()), 'dclr_fps_clouds')
+    assert torch.equal(idx.cpu(), want)
+    assert torch.equal(ops.fps_clouds(x, m).cpu(), want)             # (the workspace kernel the Python path takes: same samples)
+
+
 def test_fps_level1_large_cloud_and_temp_side_effect():
     """Level 1 through the C symbol: n > 65536 takes the global-temp kernel, 16385..65536 the workspace kernel on a
     stream-ordered scratch allocation, smaller clouds the register kernel; temp must hold the running minima over the
