@@ -623,9 +623,11 @@ extern "C" int dclr_debug_flow_stamps(unsigned long long *host_out, int blocks) 
 #endif
 
 // Which MFMA tile the split-f16 flow kernel of this build runs k neighbours on, i.e. the `width` to pack its layer-2 /
-// layer-3 weights with (dclr_pack_weight_f16): 32 (v_mfma_f32_32x32x16_f16, flow32_kernel) from 25 neighbours up -- four
-// points x 32 rows are whole tiles there, measured 2-3 % faster at k = 30 -- and 16 (v_mfma_f32_16x16x32_f16,
-// flow16_kernel) below: 4 x 20 rows would pad to 96, measured 17-20 % slower at k = 20 (profiles/NOTES.md, round 6).
+// layer-3 weights with (dclr_pack_weight_f16): 32 (v_mfma_f32_32x32x16_f16, flow32_kernel) from 29 neighbours up -- four
+// points x 32 rows are whole tiles there: 1168-1226 us against 1230-1316 per 256 x 512 points at k = 29..32 -- and 16
+// (v_mfma_f32_16x16x32_f16, flow16_kernel) below, where the rows pad: k = 25..28 (112 rows in 128) 1154-1178 against
+// 1120-1135, k = 21..24 (96 in 96, but three tiles of 32 against six of 16 per wave) 932-940 against 896-930, k = 20 (80 rows
+// in 96) 632-658 against 517-541 per 80 x 1024 points (profiles/NOTES.md, round 6).
 // -DDCLR_FLOW_TILE16 / -DDCLR_FLOW_TILE32 (A/B builds) force one form for every k.
 static bool flow_uses_tile32(int k) {
 #if defined(DCLR_FLOW_TILE16)
@@ -633,7 +635,7 @@ static bool flow_uses_tile32(int k) {
 #elif defined(DCLR_FLOW_TILE32)
     return true;
 #else
-    return (k + 3) / 4 >= 7;
+    return (k + 3) / 4 >= 8;
 #endif
 }
 extern "C" int dclr_flow_f16_tile(int k) { return flow_uses_tile32(k) ? 32 : 16; }

@@ -426,7 +426,7 @@ def head_conv_fused_f16(x: torch.Tensor, k_in: int, layers, groups: int) -> torc
 
 def flow_f16_tile(k: int) -> int:
     """Tile width the library's split-f16 flow kernel wants its layer-2 / layer-3 weights packed with when it runs k
-    neighbours per point (32 from k = 25 up, 16 below; A/B builds force one)."""
+    neighbours per point (32 from k = 29 up, 16 below; A/B builds force one)."""
     return int(lib.load().dclr_flow_f16_tile(int(k)))
 
 

@@ -242,7 +242,7 @@ int dclr_fc(int m, int n, int k, const float *x, const float *w, const float *bi
  *   order for `width`-column tiles (32: kp % 16 == 0; 16: kp % 32 == 0); kmap as in
  *   dclr_pack_weight. packed: 4 * np * kp bytes, 16-byte aligned.
  * dclr_head_conv_fused_f16: x rows hold k_in valid f32 columns (k_in % 8 == 0, k_in <= k[0]); k[l] % 16 == 0.
- * dclr_flow_embedding_fused_f16: w2p / w3p packed with width dclr_flow_f16_tile(k), kp 128 (ABI 0.2: 32 from 25
+ * dclr_flow_embedding_fused_f16: w2p / w3p packed with width dclr_flow_f16_tile(k), kp 128 (ABI 0.2: 32 from 29
  *   neighbours up, where the kernel runs on v_mfma_f32_32x32x16_f16 tiles, 16 below; ABI 0.1 read width 16 for every k). */
 int dclr_flow_f16_tile(int k);
 int dclr_pack_weight_f16(int n_out, int k_in, const float *w, const int32_t *kmap, int kp, int width, void *packed,

@@ -836,7 +836,7 @@ def test_flow_embedding_split_fp16_against_f32_path_and_float64(k, radius):
 
 @pytest.mark.parametrize('pairs, npoint', [(3, 37), (8, 16), (1, 5)])
 def test_flow_kernels_at_every_neighbour_count_with_masks_and_unfilled_slots(pairs, npoint):
-    """Both split-f16 flow kernels (flow16_kernel up to k = 24, flow32_kernel from k = 25: csrc/flow16.hip) at EVERY k from 1 to
+    """Both split-f16 flow kernels (flow16_kernel up to k = 28, flow32_kernel from k = 29: csrc/flow16.hip) at EVERY k from 1 to
     32 on hand-made neighbour lists: slots the search left unfilled (-1), neighbours beyond the radius (reference
     deepclr.py:220-225: their columns are zeroed before the max), points with NO neighbour inside the radius (all zeros),
     point counts that are not a multiple of the 4 points per workgroup, pair counts with and without the one-pair-one-XCD

@@ -320,7 +320,7 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     cloud.b, cloud.n, cloud.c, cloud.npoint, cloud.n_scales = 2, 64, 4, 16, 1
     cloud.struct_size -= 8
     assert handle.dclr_cloud_forward(ctypes.byref(cloud), None, None, None) == inval
-    assert handle.dclr_flow_f16_tile(20) == 16 and handle.dclr_flow_f16_tile(30) == 32 and handle.dclr_flow_f16_tile(32) == 32
+    assert [handle.dclr_flow_f16_tile(k) for k in (20, 28, 29, 30, 32)] == [16, 16, 32, 32, 32]
     assert handle.dclr_prepare_cloud(10, 4, None, 1, 0, 0.0, 1.0, 4, None, None, None, None) == inval
     assert handle.dclr_prepare_cloud_blocks(10, 2, 2) == inval          # start must be < nth
     assert handle.dclr_prepare_cloud_blocks(4097, 2, 1) == 2 and handle.dclr_prepare_cloud_blocks(4099, 2, 1) == 3
