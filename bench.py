@@ -758,7 +758,7 @@ def run(args):
             raise SystemExit('bench.py: --sequence runs through the pipelined runner')
         pairs_per_step = x.shape[0]
         runner = PipelinedSequence(model, depth=args.depth, ahead='features' if args.ahead == 'knn' else args.ahead,
-                                   group=args.group)
+                                   group=args.group, dense_group=bool(args.dense_group) and args.group > 1)
         runner.prefetch(x)
         runner.step(x)                       # first chunk: caches the frame the timed chunks start from
     else:

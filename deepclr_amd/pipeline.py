@@ -343,16 +343,95 @@ class PipelinedSequence(PipelinedForward):
     sampled and abstracted ONCE and serves first as source, then as template of the next pair
     (the reference's sequential mode, /root/reference/deepclr/models/base.py:97-112, caches one frame and
     runs one pair per call). step() returns the poses frame[i-1] -> frame[i] for the chunk: (T, label_dim),
-    or (T-1, label_dim) for the first chunk after reset()."""
+    or (T-1, label_dim) for the first chunk after reset().
 
-    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1):
+    dense_group (with group > 1; round 6): the chunks sampled by one launch also share ONE dense launch -- the frames of
+    the group are consecutive, so their pairs (plus the one across the border to the previous group, through the carried
+    frame) go through layer-1 halves, kNN, flow embedding, head and fully connected tail together, enqueued when the
+    group's first chunk is stepped; the other chunks of the group get slices of that result. A chunk of 16 frames alone is
+    16 pairs per dense launch sequence (seven dependent launches on the caller's stream, which then set the pace, as in
+    PipelinedForward without dense groups); ten chunks are 160."""
+
+    def __init__(self, model: DeepCLR, depth: int = 3, ahead: str = 'features', group: int = 1, dense_group: bool = False):
         if ahead == 'knn':
             raise ValueError("pairs straddle chunk borders: the kNN stage cannot run per chunk ahead of time")
         super().__init__(model, depth, ahead, group)
         self._carry: Optional[torch.Tensor] = None
+        self._seq_dense = bool(dense_group) and group > 1 and ahead == 'features'
+        self._seq_out = None                        # (chunks of the running dense group not yet stepped, outputs, their spans)
 
     def reset(self) -> None:
         self._carry = None
+
+    def in_flight(self) -> int:
+        return super().in_flight() + (len(self._seq_out[0]) if self._seq_out is not None else 0)
+
+    def _launch(self) -> None:
+        if not self._seq_dense or len(self._waiting) < 2:
+            return super()._launch()
+        xs, self._waiting = self._waiting, []
+        main = torch.cuda.current_stream()
+        side = self._streams[self._next_stream]
+        self._next_stream = (self._next_stream + 1) % self.depth
+        if not self._inputs_ready:
+            side.wait_stream(main)
+        for b in xs:
+            ev = b.__dict__.pop('_dclr_ready', None)
+            if ev is not None:
+                side.wait_event(ev)
+        with torch.cuda.stream(side), torch.no_grad():
+            big = torch.cat(xs)                                  # consecutive frames of the group's chunks
+            rows = self._model.cloud_feature_rows(big, self._model.sample(big))
+            done = torch.cuda.Event()
+            done.record(side)
+        for b in xs:
+            b.record_stream(side)
+        self._pending.append((xs, rows, done))
+
+    def _refill(self, upcoming) -> None:
+        for nxt in upcoming:
+            if self.in_flight() >= self.depth * self.group:
+                break
+            self.prefetch(nxt, flush=False)
+
+    def step(self, x: torch.Tensor, upcoming: Iterable[torch.Tensor] = (), out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not self._seq_dense:
+            return super().step(x, upcoming, out)
+        if self._seq_out is not None and self._seq_out[0] and self._seq_out[0][0] is x:
+            chunks, y_all, spans = self._seq_out                 # a chunk of the dense group already enqueued
+            chunks.pop(0)
+            lo, hi = spans.pop(0)
+            self._hold_launch = True
+            self._refill(upcoming)
+            self._hold_launch = False
+            y = y_all[lo:hi]
+            return y if out is None else out.copy_(y)
+        main = torch.cuda.current_stream()
+        if not self._pending and self._waiting and self._waiting[0] is x:
+            self._launch()                                       # end of the sequence: the group never filled
+        if self._pending and isinstance(self._pending[0][0], list) and self._pending[0][0][0] is x:
+            xs, rows, done = self._pending.popleft()
+            main.wait_event(done)
+            rows.record_stream(main)
+            had_carry = self._carry is not None
+            frames = sum(b.shape[0] for b in xs)
+            with torch.no_grad():
+                pair_rows, pairs, self._carry = self._model.sequence_rows(rows, frames, self._carry)
+                y_all = self._model.merge_rows(pair_rows, pairs) if pairs > 0 else \
+                    rows.new_empty(0, self._model.label_dim)
+            spans, start = [], 0
+            for j, b in enumerate(xs):                           # chunk j's poses: one per frame, minus the very first frame
+                n = b.shape[0] - (0 if (had_carry or j > 0) else 1)
+                spans.append((start, start + n))
+                start += n
+            self._seq_out = (list(xs[1:]), y_all, spans[1:])
+            if len(self._waiting) >= self.group:
+                self._launch()
+            self._refill(upcoming)
+            lo, hi = spans[0]
+            y = y_all[lo:hi]
+            return y if out is None else out.copy_(y)
+        return super().step(x, upcoming, out)                    # a chunk sampled alone
 
     def _dense(self, f_rows: torch.Tensor, x: torch.Tensor, prep=None, out=None) -> torch.Tensor:
         pair_rows, pairs, self._carry = self._model.sequence_rows(f_rows, x.shape[0], self._carry)

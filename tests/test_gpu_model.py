@@ -788,6 +788,16 @@ def test_sequence_mode_computes_each_frame_once_and_matches_pairwise_calls():
     assert torch.equal(chunked.predict(frames[0]), one.predict(frames[0]))      # the cached frame carries on
     piped = torch.cat(list(PipelinedSequence(model, depth=2).run([frames[:1], frames[1:4], frames[4:]])))
     assert torch.equal(piped, want)
+    # round 6: the chunks sampled by one launch share one dense launch (dense_group): the same poses, whatever the chunking,
+    # also across a group border (the carried frame) and for a stream that ends inside a group
+    for group, chunks in ((2, [frames[:1], frames[1:4], frames[4:]]), (3, [frames[:2], frames[2:4], frames[4:5], frames[5:]]),
+                          (2, [frames[i:i + 1] for i in range(6)]), (4, [frames[:3], frames[3:]])):
+        runner = PipelinedSequence(model, depth=2, group=group, dense_group=True)
+        outs = list(runner.run(chunks))
+        assert [o.shape[0] for o in outs] == [c.shape[0] - (1 if i == 0 else 0) for i, c in enumerate(chunks)]
+        assert torch.equal(torch.cat(outs), want), group
+        more = list(runner.run([frames[:2], frames[2:3]]))                        # the sequence goes on: frame 5 -> 0 -> 1 -> 2
+        assert more[0].shape[0] == 2 and torch.equal(more[1][0], want[1]) and torch.equal(more[0][1], want[0])
     y_o = orc(torch.stack((frames[2], frames[3])).cpu())                        # pair (frame 2 -> frame 3)
     _close(want[2:3], y_o)
 
