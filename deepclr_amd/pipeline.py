@@ -361,7 +361,9 @@ class PipelinedSequence(PipelinedForward):
         self._seq_out = None                        # (chunks of the running dense group not yet stepped, outputs, their spans)
 
     def reset(self) -> None:
+        """Start a new sequence: no carried frame, and nothing left of a dense group whose chunks were not all stepped."""
         self._carry = None
+        self._seq_out = None
 
     def in_flight(self) -> int:
         return super().in_flight() + (len(self._seq_out[0]) if self._seq_out is not None else 0)
