@@ -898,7 +898,7 @@ def test_flow_kernels_at_every_neighbour_count_with_masks_and_unfilled_slots(pai
         _close(e32[:, :256], want.float().cpu(), stage='f32 flow kernel k=%d vs float64' % k)
         assert torch.equal(e16[:, 256:259], f_rows[:half, 64:67]) and bool((e16[:, 259:] == 0).all())
         assert torch.equal(e16 == 0, e32 == 0)                              # the same columns are empty on both paths
-    assert tiles <= {16, 32} and 32 in tiles                             # (an A/B build may force one tile for every k)
+    assert tiles <= {16, 32}                                             # (both in the product build: tests/test_host.py; an A/B build forces one)
 
 
 def test_forward_with_augmentation_matrix_m_transforms_in_place_and_matches_oracle():
